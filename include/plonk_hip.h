@@ -1,0 +1,173 @@
+/* plonk_hip.h -- C ABI of the MI355X (gfx950) PLONK prover hot path.
+ *
+ * Every entry point replaces one seam of the reference's `backend_new` crate (paths below are
+ * relative to the reference tree).  The reference has no FFI of its own: these are the Rust
+ * function signatures its protocol layer calls, restated as extern "C" with plain pointers.
+ *
+ * Conventions
+ *  - Fr: 32 bytes = 4 x u64 little-endian limbs in Montgomery form (R = 2^256), the in-memory
+ *    image of ark_bls12_381::Fr that backend_new/src/field.rs:18 wraps.
+ *  - Fq: 48 bytes = 6 x u64 little-endian limbs, Montgomery form (R = 2^384).
+ *  - G1 affine: plonk_g1 = x || y (Fq each) + infinity flag, the fields of ark's G1Affine that
+ *    backend_new/src/curve.rs:33 wraps.
+ *  - All vectors are natural order in and out (fft.rs:300-318).
+ *  - Every function returns PLONK_OK (0) or a negative status and never unwinds; the message is
+ *    at plonk_last_error(ctx).  Conditions that panic in the reference (fft.rs:24,44;
+ *    kzg.rs:232-238; prover.rs:185,290,447) return PLONK_E_INVALID.
+ *  - A ctx owns one HIP device + stream and must be used from one host thread at a time.
+ *    Handles (srs, pk) are immutable after creation and may be shared by contexts on the same
+ *    device.  The caller owns every host buffer; the library borrows it for the call only.
+ *  - Pointers named *_dev are device pointers obtained from plonk_dev_alloc (or any hipMalloc).
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLONK_OK 0
+#define PLONK_E_INVALID (-1) /* bad size / degree / argument (reference: panic) */
+#define PLONK_E_HIP (-2)     /* HIP runtime failure */
+#define PLONK_E_NOMEM (-3)
+#define PLONK_E_INTERNAL (-4)
+
+#define PLONK_NTT_INVERSE 1u /* fft.rs:42 ifft (scaled by 1/n) */
+#define PLONK_NTT_COSET 2u   /* fft.rs:121 coset_fft / :140 coset_ifft */
+
+typedef struct plonk_ctx plonk_ctx;
+typedef struct plonk_srs plonk_srs;
+typedef struct plonk_pk plonk_pk;
+
+typedef struct plonk_fr {
+    uint64_t l[4];
+} plonk_fr;
+
+typedef struct plonk_g1 {
+    uint64_t x[6];
+    uint64_t y[6];
+    uint8_t infinity;
+    uint8_t pad[7];
+} plonk_g1;
+
+/* types.rs:74-114 `Proof`: 9 G1 commitments + 6 evaluations, in the reference's field order.
+ * Evaluations are Montgomery-form Fr like every other scalar in this ABI. */
+typedef struct plonk_proof {
+    plonk_g1 a_comm, b_comm, c_comm, z_comm, t_lo_comm, t_mid_comm, t_hi_comm;
+    plonk_fr a_eval, b_eval, c_eval, s_sigma1_eval, s_sigma2_eval, z_omega_eval;
+    plonk_g1 w_zeta_comm, w_zeta_omega_comm;
+} plonk_proof;
+
+#define PLONK_PROOF_WIRE_BYTES 624 /* 9 x 48-byte compressed G1 + 6 x 32-byte canonical LE Fr */
+
+/* ---- context ---- */
+int32_t plonk_ctx_create(int32_t device, plonk_ctx** out);
+void plonk_ctx_destroy(plonk_ctx* ctx);
+const char* plonk_last_error(const plonk_ctx* ctx);
+int32_t plonk_sync(plonk_ctx* ctx);
+/* The HIP stream every kernel of this ctx is launched on (a hipStream_t). */
+void* plonk_ctx_stream(plonk_ctx* ctx);
+
+/* ---- device memory (thin wrappers so an FFI caller needs no HIP binding) ---- */
+int32_t plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out_dev);
+int32_t plonk_dev_free(plonk_ctx* ctx, void* dev);
+int32_t plonk_dev_upload(plonk_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int32_t plonk_dev_download(plonk_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- NTT: replaces fft / ifft / coset_fft / coset_ifft and Domain::{fft,ifft,coset_fft,
+ * coset_ifft} (backend_new/src/fft.rs:23,42,121,140,220-248).
+ * In place over `batch` vectors of 2^log_n Fr, vector b at data + b*stride (elements).
+ * flags: PLONK_NTT_INVERSE, PLONK_NTT_COSET.  `shift` is the coset generator k (Montgomery
+ * Fr); NULL means 7, the value prover.rs:367 uses.  The inverse transform scales by 1/n and,
+ * with COSET, by k^-i, exactly as fft.rs:52-56,147-152.  log_n in [0, 32]. */
+int32_t plonk_ntt_dev(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags,
+                      const plonk_fr* shift, uint32_t batch, size_t stride);
+/* Same over a host buffer (upload, transform, download). */
+int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t flags,
+                  const plonk_fr* shift, uint32_t batch, size_t stride);
+
+/* ---- SRS + commit: replaces Srs (kzg.rs:26-35), Commitment::commit (kzg.rs:231-245) and
+ * G1Projective::msm (curve.rs:169-173). ---- */
+/* Upload g1_powers[0..n) (kzg.rs:28).  Points must be on the curve; infinity allowed. */
+int32_t plonk_srs_upload(plonk_ctx* ctx, const plonk_g1* g1_powers, size_t n, plonk_srs** out);
+/* [tau^i]_1 for i in [0, n) generated on the device from a known tau (Montgomery Fr):
+ * the group elements of Srs::from_tau (kzg.rs:71-94).  For synthetic benchmarks and tests. */
+int32_t plonk_srs_from_tau(plonk_ctx* ctx, const plonk_fr* tau, size_t n, plonk_srs** out);
+size_t plonk_srs_len(const plonk_srs* srs);
+int32_t plonk_srs_download(plonk_ctx* ctx, const plonk_srs* srs, size_t first, size_t count, plonk_g1* out);
+void plonk_srs_free(plonk_srs* srs);
+/* commit(poly, srs): MSM of coeffs[0..len) against g1_powers[0..len), result affine.
+ * len > srs length -> PLONK_E_INVALID (the reference panics, kzg.rs:232-238).  len == 0 or an
+ * all-zero polynomial gives the identity. */
+int32_t plonk_commit(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_host, size_t len,
+                     plonk_g1* out);
+int32_t plonk_commit_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_dev, size_t len,
+                         plonk_g1* out);
+/* G1Projective::msm(points, scalars) (curve.rs:169-173) over host arrays, result affine. */
+int32_t plonk_msm(plonk_ctx* ctx, const plonk_g1* points_host, const plonk_fr* scalars_host, size_t n,
+                  plonk_g1* out);
+
+/* ---- proving key: replaces preprocess (plonk/preprocess.rs:104-186) and ProvingKey
+ * (plonk/types.rs:12).  Inputs are the per-gate selector vectors (constraint.rs:385-393) and the
+ * S_sigma evaluation vectors of Permutation::compute (permutation.rs:113-126), each n = 2^log_n
+ * Montgomery Fr on the host.  k1, k2 are the coset generators (permutation.rs:61-62).
+ * pi_positions are ConstraintSystem::public_input_positions.  The key keeps, resident on the
+ * device, the nine coefficient vectors (q_M..q_C, S_sigma1..3, L1) and their evaluations on
+ * the 4n coset 7*H (what prover.rs:380-392 recomputes for every proof). */
+int32_t plonk_pk_create(plonk_ctx* ctx, uint32_t log_n, const plonk_fr* q_m, const plonk_fr* q_l,
+                        const plonk_fr* q_r, const plonk_fr* q_o, const plonk_fr* q_c,
+                        const plonk_fr* s_sigma1, const plonk_fr* s_sigma2, const plonk_fr* s_sigma3,
+                        const plonk_fr* k1, const plonk_fr* k2, const uint32_t* pi_positions,
+                        size_t n_pi_positions, plonk_pk** out);
+void plonk_pk_free(plonk_pk* pk);
+/* The eight verification-key commitments of preprocess.rs:130-138, in the order
+ * q_m, q_l, q_r, q_o, q_c, s_sigma1, s_sigma2, s_sigma3. */
+int32_t plonk_pk_commitments(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, plonk_g1 out[8]);
+/* Coefficients (normalised length returned in *len) of one key polynomial, index as above
+ * plus 8 = L1; for tests. */
+int32_t plonk_pk_poly(plonk_ctx* ctx, const plonk_pk* pk, uint32_t which, plonk_fr* out_host, size_t* len);
+
+/* ---- round-3 quotient: replaces the body of Prover::round3 (plonk/prover.rs:364-457 and the
+ * coset iNTT at :497).  a, b, c, z are blinded coefficient vectors on the device, zero-padded
+ * to 4n Fr each; pi is the public-input polynomial (n coefficients, zero-padded to 4n) or NULL
+ * when there are no public inputs.  The inputs are overwritten with their coset evaluations.
+ * t_out_dev receives the 4n coefficients of t(X). */
+int32_t plonk_quotient_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, plonk_fr* a_dev, plonk_fr* b_dev,
+                                 plonk_fr* c_dev, plonk_fr* z_dev, plonk_fr* pi_dev, const plonk_fr* alpha,
+                                 const plonk_fr* beta, const plonk_fr* gamma, plonk_fr* t_out_dev);
+
+/* ---- whole prover: replaces Prover::new + Prover::prove (plonk/prover.rs:39-62).
+ * a/b/c_evals: ConstraintSystem::get_wire_values (constraint.rs:401-410), n Montgomery Fr each.
+ * blinding[11] = b1..b11 in the order the reference draws them from its RNG (prover.rs:189-194,
+ * 310-312, 537-538); the caller supplies the randomness. */
+int32_t plonk_prove_3wire(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, const plonk_fr* a_evals,
+                          const plonk_fr* b_evals, const plonk_fr* c_evals, const plonk_fr* public_inputs,
+                          size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out);
+
+/* ---- encodings (host only, no device work) ---- */
+/* G1Affine::to_compressed_bytes (curve.rs:84-88). */
+int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]);
+/* Fr::to_bytes (field.rs:106-114): canonical little-endian. */
+int32_t plonk_fr_to_bytes(const plonk_fr* a, uint8_t out[32]);
+/* Fr::from_bytes (field.rs:117-125): PLONK_E_INVALID when the integer is >= r. */
+int32_t plonk_fr_from_bytes(const uint8_t in[32], plonk_fr* out);
+/* 624-byte wire image: a,b,c,z,t_lo,t_mid,t_hi compressed, six evaluations, w_zeta,
+ * w_zeta_omega compressed (the field order of trace.rs:255-332 CompactProof). */
+int32_t plonk_proof_serialize(const plonk_proof* proof, uint8_t out[PLONK_PROOF_WIRE_BYTES]);
+/* Transcript::squeeze_challenge chain of the prover (transcript.rs:39-131), exposed so callers
+ * can re-derive beta, gamma, alpha, zeta, v, u from a proof: out[6] Montgomery Fr. */
+int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_inputs, size_t n_public_inputs,
+                               plonk_fr out[6]);
+
+/* ---- measurement helper: achieved Fr / Fq Montgomery multiplications per second of a
+ * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
+ * priced against).  which: 0 = Fr, 1 = Fq. */
+int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

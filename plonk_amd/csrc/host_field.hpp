@@ -1,0 +1,241 @@
+// Host-side BLS12-381 Fr / Fq arithmetic (64-bit limbs, Montgomery form, same byte image as the
+// device's 32-bit-limb elements) and G1 helpers.  Used for the O(1)/O(log n) protocol glue that
+// sits between device kernels: roots of unity (backend_new/src/field.rs:167-182), challenge
+// arithmetic, point (de)compression (curve.rs:84-88).  No bulk data ever goes through these.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <array>
+
+namespace plonk {
+namespace host {
+
+typedef unsigned __int128 u128;
+
+template <int N>
+struct HLimbs {
+    uint64_t l[N];
+    bool operator==(const HLimbs& o) const { return memcmp(l, o.l, sizeof(l)) == 0; }
+    bool operator!=(const HLimbs& o) const { return !(*this == o); }
+};
+
+struct HFrP {
+    static constexpr int N = 4;
+    static constexpr uint64_t INV = 0xfffffffeffffffffull;
+    static constexpr uint64_t P[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull,
+                                      0x73eda753299d7d48ull};
+    static constexpr uint64_t ONE[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull,
+                                        0x1824b159acc5056full};
+    static constexpr uint64_t R2[4] = {0xc999e990f3f29c6dull, 0x2b6cedcb87925c23ull, 0x05d314967254398full,
+                                       0x0748d9d99f59ff11ull};
+};
+
+struct HFqP {
+    static constexpr int N = 6;
+    static constexpr uint64_t INV = 0x89f3fffcfffcfffdull;
+    static constexpr uint64_t P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
+                                      0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+    static constexpr uint64_t ONE[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull,
+                                        0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};
+    static constexpr uint64_t R2[6] = {0xf4df1f341c341746ull, 0x0a76e6a609d104f1ull, 0x8de5476c4c95b6d5ull,
+                                       0x67eb88a9939d83c0ull, 0x9a793e85b519952dull, 0x11988fe592cae3aaull};
+};
+
+template <class F>
+struct Field {
+    static constexpr int N = F::N;
+    typedef HLimbs<F::N> E;
+
+    static E zero() {
+        E r;
+        memset(r.l, 0, sizeof(r.l));
+        return r;
+    }
+    static E one() {
+        E r;
+        for (int i = 0; i < N; ++i) r.l[i] = F::ONE[i];
+        return r;
+    }
+    static bool is_zero(const E& a) {
+        uint64_t o = 0;
+        for (int i = 0; i < N; ++i) o |= a.l[i];
+        return o == 0;
+    }
+    static bool geq_p(const E& a) {
+        for (int i = N - 1; i >= 0; --i) {
+            if (a.l[i] > F::P[i]) return true;
+            if (a.l[i] < F::P[i]) return false;
+        }
+        return true;
+    }
+    static void sub_p(E& a) {
+        u128 borrow = 0;
+        for (int i = 0; i < N; ++i) {
+            u128 d = (u128)a.l[i] - F::P[i] - borrow;
+            a.l[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+    }
+    static E add(const E& a, const E& b) {
+        E r;
+        u128 c = 0;
+        for (int i = 0; i < N; ++i) {
+            c += (u128)a.l[i] + b.l[i];
+            r.l[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        if (geq_p(r)) sub_p(r);
+        return r;
+    }
+    static E sub(const E& a, const E& b) {
+        E r;
+        u128 borrow = 0;
+        for (int i = 0; i < N; ++i) {
+            u128 d = (u128)a.l[i] - b.l[i] - borrow;
+            r.l[i] = (uint64_t)d;
+            borrow = (d >> 64) & 1;
+        }
+        if (borrow) {
+            u128 c = 0;
+            for (int i = 0; i < N; ++i) {
+                c += (u128)r.l[i] + F::P[i];
+                r.l[i] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
+        return r;
+    }
+    static E neg(const E& a) { return sub(zero(), a); }
+    static E mul(const E& a, const E& b) {
+        uint64_t t[N + 2];
+        memset(t, 0, sizeof(t));
+        for (int i = 0; i < N; ++i) {
+            u128 c = 0;
+            for (int j = 0; j < N; ++j) {
+                c += (u128)a.l[j] * b.l[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[N];
+            t[N] = (uint64_t)c;
+            t[N + 1] = (uint64_t)(c >> 64);
+            uint64_t m = t[0] * F::INV;
+            c = (u128)m * F::P[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < N; ++j) {
+                c += (u128)m * F::P[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[N];
+            t[N - 1] = (uint64_t)c;
+            t[N] = t[N + 1] + (uint64_t)(c >> 64);
+        }
+        E r;
+        for (int i = 0; i < N; ++i) r.l[i] = t[i];
+        if (t[N] || geq_p(r)) sub_p(r);
+        return r;
+    }
+    static E sqr(const E& a) { return mul(a, a); }
+    // canonical little-endian limbs -> Montgomery
+    static E to_mont(const E& a) {
+        E r2;
+        for (int i = 0; i < N; ++i) r2.l[i] = F::R2[i];
+        return mul(a, r2);
+    }
+    static E from_mont(const E& a) {
+        E o = zero();
+        o.l[0] = 1;
+        return mul(a, o);
+    }
+    static E from_u64(uint64_t v) {
+        E a = zero();
+        a.l[0] = v;
+        return to_mont(a);
+    }
+    static E pow_u64(const E& a, uint64_t e) {
+        E r = one(), b = a;
+        while (e) {
+            if (e & 1) r = mul(r, b);
+            b = sqr(b);
+            e >>= 1;
+        }
+        return r;
+    }
+    // exponent given as canonical limbs
+    static E pow_limbs(const E& a, const uint64_t* e, int nl) {
+        E r = one();
+        for (int i = nl * 64 - 1; i >= 0; --i) {
+            r = sqr(r);
+            if ((e[i / 64] >> (i % 64)) & 1) r = mul(r, a);
+        }
+        return r;
+    }
+    static E inv(const E& a) {
+        uint64_t e[N];
+        for (int i = 0; i < N; ++i) e[i] = F::P[i];
+        e[0] -= 2;  // p is odd and p[0] >= 2 for both fields
+        return pow_limbs(a, e, N);
+    }
+};
+
+typedef Field<HFrP> Fr;
+typedef Field<HFqP> Fq;
+typedef Fr::E fr_h;
+typedef Fq::E fq_h;
+
+// field.rs:167-182 -- primitive 2^log_n-th root of unity: TWO_ADIC_ROOT^(2^(32-log_n)),
+// TWO_ADIC_ROOT = 7^((r-1)/2^32).
+inline fr_h fr_root_of_unity(unsigned log_n) {
+    // (r-1)/2^32 as canonical limbs
+    static const uint64_t T[4] = {0xfffe5bfeffffffffull, 0x09a1d80553bda402ull, 0x299d7d483339d808ull,
+                                  0x0000000073eda753ull};
+    fr_h root = Fr::pow_limbs(Fr::from_u64(7), T, 4);
+    for (unsigned i = log_n; i < 32; ++i) root = Fr::sqr(root);
+    return root;
+}
+
+// Canonical (non-Montgomery) 32-byte little-endian image of an Fr (field.rs:106-114).
+inline void fr_to_bytes_le(const fr_h& a_mont, uint8_t out[32]) {
+    fr_h c = Fr::from_mont(a_mont);
+    memcpy(out, c.l, 32);
+}
+// field.rs:117-125 -- false when the integer is >= r.
+inline bool fr_from_bytes_le(const uint8_t in[32], fr_h* out_mont) {
+    fr_h c;
+    memcpy(c.l, in, 32);
+    if (Fr::geq_p(c)) return false;
+    *out_mont = Fr::to_mont(c);
+    return true;
+}
+
+struct G1AffineH {
+    fq_h x, y;  // Montgomery
+    bool inf;
+};
+
+// ZCash/IETF 48-byte compressed encoding (the serialize_compressed of ark-bls12-381 0.4.0 that
+// curve.rs:84-88 calls): big-endian x, bit 7 compressed, bit 6 infinity, bit 5 y > (q-1)/2.
+inline void g1_compress(const G1AffineH& p, uint8_t out[48]) {
+    memset(out, 0, 48);
+    if (p.inf) {
+        out[0] = 0xC0;
+        return;
+    }
+    fq_h x = Fq::from_mont(p.x), y = Fq::from_mont(p.y);
+    for (int i = 0; i < 6; ++i)
+        for (int b = 0; b < 8; ++b) out[47 - (i * 8 + b)] = (uint8_t)(x.l[i] >> (8 * b));
+    out[0] |= 0x80;
+    // y > (q-1)/2  <=>  2y > q - 1  <=>  2y >= q + 1 > q  (q odd) <=> y > q - y
+    fq_h ny = Fq::neg(Fq::to_mont(y));  // q - y (Montgomery)
+    fq_h nyc = Fq::from_mont(ny);
+    bool larger = false;
+    for (int i = 5; i >= 0; --i) {
+        if (y.l[i] > nyc.l[i]) { larger = true; break; }
+        if (y.l[i] < nyc.l[i]) { larger = false; break; }
+    }
+    if (larger) out[0] |= 0x20;
+}
+
+}  // namespace host
+}  // namespace plonk

@@ -1,0 +1,343 @@
+// Number-theoretic transform over BLS12-381 Fr for gfx950.
+//
+// Replaces fft / ifft / coset_fft / coset_ifft of backend_new/src/fft.rs:23-157 (natural order
+// in and out; inverse scaled by 1/n; coset variants scale coefficient i by k^i before / k^-i
+// after).  The reference runs log2(N) radix-2 sweeps over the whole vector; here a transform of
+// N = N_1 * ... * N_P points is P sweeps over HBM.  Sweep p loads tiles of N_p x C elements
+// into LDS (C consecutive elements per row, so every global access is a C*32-byte run), runs
+// log2(N_p) radix-2 decimation-in-frequency stages out of LDS, applies the step's twiddle
+// w_N^(i_{p+1} * S_{p+1} * K_p) and stores.  The first sweep reads `data` and writes the
+// intermediate image, the last reads that image and writes natural order back to `data`.
+//
+// Index algebra: address = hi * (N_p * S_p) + d * S_p + lo with S_p = N_{p+1}...N_P; sweep p
+// replaces digit d = i_p by k_p.  hi holds k_1..k_{p-1} (k_1 most significant), lo holds
+// i_{p+1}..i_P.  K_p = k_1 + N_1 k_2 + ... + N_1..N_{p-1} k_p.  The output index of the whole
+// transform is K_P.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace plonk {
+
+static constexpr int NTT_MAX_PASSES = 4;
+static constexpr int NTT_TILE_LOG = 11;      // elements per LDS tile = 2^11 (64 KiB of Fr)
+static constexpr int NTT_SUBTW_LOG = 11;     // sub_tw holds w_{2^11}^j, j < 2^10
+static constexpr int NTT_THREADS = 256;
+
+struct NttPassArgs {
+    const fr_t* in;
+    fr_t* out;
+    const fr_t* pre;     // [2^R] multiplies input digit d (nullable)
+    const fr_t* post;    // [2^R] multiplies output digit k (nullable)
+    const fr_t* sub_tw;  // w_{2^11}^j
+    const fr_t* tw_lo;   // w_N^j, j < 2^logL
+    const fr_t* tw_hi;   // w_N^(j << logL)
+    uint32_t log_n, R, log_s, log_c, log_h, log_l;
+    uint32_t n_prev;              // number of earlier sweeps
+    uint32_t r_prev[NTT_MAX_PASSES];
+    uint32_t log_s_next;          // log2 S_{p+1} (non-last sweeps)
+    uint32_t is_last;
+    uint64_t batch_stride;
+};
+
+__device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// k_1 + N_1 k_2 + ... from hi = k_1 * (N_2..N_{q}) + ... + k_q  (mixed-radix digit reversal)
+__device__ __forceinline__ uint32_t digits_rev(uint32_t hi, uint32_t log_h, uint32_t n_prev, const uint32_t* r_prev) {
+    uint32_t K = 0, out_shift = 0, rem = log_h;
+    for (uint32_t q = 0; q < n_prev; ++q) {
+        rem -= r_prev[q];
+        uint32_t digit = (hi >> rem) & ((1u << r_prev[q]) - 1u);
+        K |= digit << out_shift;
+        out_shift += r_prev[q];
+    }
+    return K;
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    const uint32_t R = p.R, log_c = p.log_c;
+    const uint32_t Np = 1u << R, C = 1u << log_c;
+    const uint32_t T = Np << log_c;
+    // last sweep: rows are contiguous in memory -> image [c][d] with one element of padding per
+    // row; other sweeps: image [d][c].
+    const bool rowmajor = p.is_last != 0;
+    const uint32_t plane = rowmajor ? (C * (Np + 1)) : T;
+    uint4* lds_lo = lds;
+    uint4* lds_hi = lds + plane;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const fr_t* in = p.in + (size_t)blockIdx.y * p.batch_stride;
+    fr_t* out = p.out + (size_t)blockIdx.y * p.batch_stride;
+
+    // ---- tile geometry ----
+    uint32_t hi = 0, lo_base = 0, k1_base = 0, rest = 0, log_h_rest = 0;
+    if (!p.is_last) {
+        const uint32_t tiles_per_hi_log = p.log_s - log_c;
+        hi = tile >> tiles_per_hi_log;
+        lo_base = (tile & ((1u << tiles_per_hi_log) - 1u)) << log_c;
+    } else if (p.n_prev) {
+        const uint32_t r1 = p.r_prev[0];
+        log_h_rest = p.log_h - r1;
+        const uint32_t k1_tiles_log = r1 - log_c;
+        k1_base = (tile & ((1u << k1_tiles_log) - 1u)) << log_c;
+        rest = tile >> k1_tiles_log;
+    }
+    auto lds_index = [&](uint32_t d, uint32_t c) -> uint32_t { return rowmajor ? (c * (Np + 1) + d) : ((d << log_c) + c); };
+
+    // ---- load ----
+    for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+        uint32_t c, d;
+        size_t addr;
+        if (rowmajor) {
+            d = e & (Np - 1);
+            c = e >> R;
+            const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
+            addr = ((size_t)hi_c << R) + d;
+        } else {
+            c = e & (C - 1);
+            d = e >> log_c;
+            addr = ((size_t)hi << (R + p.log_s)) + ((size_t)d << p.log_s) + lo_base + c;
+        }
+        fr_t x = ld(in + addr);
+        if (p.pre) x = fr_mul(x, ld(p.pre + d));
+        const uint32_t li = lds_index(d, c);
+        lds_lo[li] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        lds_hi[li] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    }
+    __syncthreads();
+
+    // ---- log2(Np) decimation-in-frequency stages; result lands bit-reversed in d ----
+    for (uint32_t s = R; s-- > 0;) {
+        const uint32_t m = 1u << s;
+        for (uint32_t q = tid; q < (T >> 1); q += NTT_THREADS) {
+            uint32_t c, bq;
+            if (rowmajor) {
+                bq = q & ((Np >> 1) - 1);
+                c = q >> (R - 1);
+            } else {
+                c = q & (C - 1);
+                bq = q >> log_c;
+            }
+            const uint32_t j = bq & (m - 1);
+            const uint32_t d0 = ((bq >> s) << (s + 1)) + j;
+            const uint32_t i0 = lds_index(d0, c), i1 = lds_index(d0 + m, c);
+            fr_t u, v;
+            {
+                uint4 a = lds_lo[i0], b = lds_hi[i0];
+                u.l[0] = a.x; u.l[1] = a.y; u.l[2] = a.z; u.l[3] = a.w; u.l[4] = b.x; u.l[5] = b.y; u.l[6] = b.z; u.l[7] = b.w;
+                a = lds_lo[i1]; b = lds_hi[i1];
+                v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+            }
+            fr_t sum = fr_add(u, v);
+            fr_t dif = fr_sub(u, v);
+            if (s != 0) dif = fr_mul(dif, ld(p.sub_tw + ((size_t)j << (NTT_SUBTW_LOG - 1 - s))));
+            lds_lo[i0] = make_uint4(sum.l[0], sum.l[1], sum.l[2], sum.l[3]);
+            lds_hi[i0] = make_uint4(sum.l[4], sum.l[5], sum.l[6], sum.l[7]);
+            lds_lo[i1] = make_uint4(dif.l[0], dif.l[1], dif.l[2], dif.l[3]);
+            lds_hi[i1] = make_uint4(dif.l[4], dif.l[5], dif.l[6], dif.l[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store ----
+    const uint32_t K_hi = p.is_last ? 0u : digits_rev(hi, p.log_h, p.n_prev, p.r_prev);
+    for (uint32_t e = tid; e < T; e += NTT_THREADS) {
+        const uint32_t c = e & (C - 1);
+        const uint32_t k = e >> log_c;
+        const uint32_t li = lds_index(brev(k, R), c);
+        fr_t x;
+        {
+            uint4 a = lds_lo[li], b = lds_hi[li];
+            x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
+        }
+        if (p.post) x = fr_mul(x, ld(p.post + k));
+        size_t addr;
+        if (p.is_last) {
+            const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
+            const uint32_t K = digits_rev(hi_c, p.log_h, p.n_prev, p.r_prev);
+            addr = (size_t)K + ((size_t)k << p.log_h);
+        } else {
+            // twiddle w_N^(i_next * S_next * K_p),  K_p = K_hi + 2^log_h * k
+            const uint32_t lo = lo_base + c;
+            const uint64_t inext_s = (uint64_t)(lo >> p.log_s_next) << p.log_s_next;
+            const uint64_t Kp = (uint64_t)K_hi + ((uint64_t)k << p.log_h);
+            const uint64_t ex = (inext_s * Kp) & (((uint64_t)1 << p.log_n) - 1);
+            if (ex) {
+                const fr_t wl = ld(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
+                const fr_t wh = ld(p.tw_hi + (ex >> p.log_l));
+                x = fr_mul(x, fr_mul(wl, wh));
+            }
+            addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
+        }
+        st(out + addr, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct NttPlan {
+    uint32_t log_n = 0, flags = 0, n_pass = 0;
+    uint32_t R[NTT_MAX_PASSES] = {0, 0, 0, 0};
+    uint32_t log_l = 0;
+    DevBuf<fr_t> sub_tw, tw_lo, tw_hi;
+    DevBuf<fr_t> pre[NTT_MAX_PASSES], post[NTT_MAX_PASSES];
+    host::fr_h shift;
+};
+
+Ctx::~Ctx() {
+    plans.clear();
+    ntt_tmp.release();
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+static void upload(DevBuf<fr_t>& buf, const std::vector<host::fr_h>& v) {
+    buf.alloc(v.size());
+    if (!v.empty()) HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+}
+
+static std::vector<host::fr_h> powers(const host::fr_h& base, size_t count) {
+    std::vector<host::fr_h> v(count);
+    host::fr_h acc = host::Fr::one();
+    for (size_t i = 0; i < count; ++i) {
+        v[i] = acc;
+        acc = host::Fr::mul(acc, base);
+    }
+    return v;
+}
+
+static std::unique_ptr<NttPlan> build_plan(uint32_t log_n, uint32_t flags, const host::fr_h& shift) {
+    using host::Fr;
+    std::unique_ptr<NttPlan> pl(new NttPlan());
+    pl->log_n = log_n;
+    pl->flags = flags;
+    pl->shift = shift;
+    const bool inverse = flags & NTT_INVERSE, coset = flags & NTT_COSET;
+    // sweep sizes
+    uint32_t P = log_n <= NTT_TILE_LOG ? 1 : (log_n + 7) / 8;
+    PLONK_REQUIRE(P <= NTT_MAX_PASSES, "ntt: log_n out of range");
+    pl->n_pass = P;
+    for (uint32_t p = 0; p < P; ++p) pl->R[p] = log_n / P + (p < log_n % P ? 1 : 0);
+    // twiddle tables of w = w_N (or its inverse)
+    host::fr_h w = host::fr_root_of_unity(log_n);
+    if (inverse) w = Fr::inv(w);
+    {
+        host::fr_h w11 = host::fr_root_of_unity(NTT_SUBTW_LOG);
+        if (inverse) w11 = Fr::inv(w11);
+        upload(pl->sub_tw, powers(w11, (size_t)1 << (NTT_SUBTW_LOG - 1)));
+    }
+    if (P > 1) {
+        pl->log_l = (log_n + 1) / 2;
+        upload(pl->tw_lo, powers(w, (size_t)1 << pl->log_l));
+        upload(pl->tw_hi, powers(Fr::pow_u64(w, (uint64_t)1 << pl->log_l), (size_t)1 << (log_n - pl->log_l)));
+    }
+    // per-digit scale tables
+    host::fr_h n_inv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
+    if (coset && !inverse) {
+        // coefficient i is scaled by g^i (fft.rs:129-133); i = sum_p d_p * S_p
+        uint32_t log_s = log_n;
+        for (uint32_t p = 0; p < P; ++p) {
+            log_s -= pl->R[p];
+            upload(pl->pre[p], powers(Fr::pow_u64(shift, (uint64_t)1 << log_s), (size_t)1 << pl->R[p]));
+        }
+    }
+    if (inverse) {
+        // output K is scaled by 1/n (fft.rs:52-56) and, for the coset form, g^-K (fft.rs:147-152);
+        // K = sum_p k_p * 2^(R_1+..+R_{p-1})
+        host::fr_h g_inv = coset ? Fr::inv(shift) : Fr::one();
+        uint32_t log_m = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const bool last = p + 1 == P;
+            if (coset || last) {
+                std::vector<host::fr_h> v = powers(Fr::pow_u64(g_inv, (uint64_t)1 << log_m), (size_t)1 << pl->R[p]);
+                if (last)
+                    for (auto& x : v) x = Fr::mul(x, n_inv);
+                upload(pl->post[p], v);
+            }
+            log_m += pl->R[p];
+        }
+    }
+    return pl;
+}
+
+static uint64_t plan_key(uint32_t log_n, uint32_t flags) { return (uint64_t)log_n | ((uint64_t)(flags & 3u) << 8); }
+
+static NttPlan* get_plan_shift(Ctx* ctx, uint32_t log_n, uint32_t flags, const host::fr_h& shift) {
+    // plans are cached per (log_n, flags); a different coset shift rebuilds the entry
+    const uint64_t key = plan_key(log_n, flags);
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end() && (!(flags & NTT_COSET) || it->second->shift == shift)) return it->second.get();
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // a replaced plan may still be in use
+    std::shared_ptr<NttPlan> pl(build_plan(log_n, flags, shift).release());
+    ctx->plans[key] = pl;
+    return pl.get();
+}
+
+NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
+    return get_plan_shift(ctx, log_n, flags, host::Fr::from_u64(7));
+}
+
+static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride) {
+    const uint32_t log_n = pl->log_n, P = pl->n_pass;
+    if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    fr_t* tmp = nullptr;
+    if (P > 1) {
+        const size_t need = (size_t)(batch - 1) * batch_stride + ((size_t)1 << log_n);
+        ctx->ntt_tmp.ensure(need);
+        tmp = ctx->ntt_tmp.p;
+    }
+    uint32_t log_h = 0;
+    uint32_t log_s = log_n;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t R = pl->R[p];
+        log_s -= R;
+        const bool last = p + 1 == P;
+        NttPassArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = (p == 0) ? data : tmp;
+        a.out = last ? data : tmp;
+        a.pre = pl->pre[p].p;
+        a.post = pl->post[p].p;
+        a.sub_tw = pl->sub_tw.p;
+        a.tw_lo = pl->tw_lo.p;
+        a.tw_hi = pl->tw_hi.p;
+        a.log_n = log_n;
+        a.R = R;
+        a.log_s = log_s;
+        a.log_h = log_h;
+        a.log_l = pl->log_l;
+        a.n_prev = p;
+        for (uint32_t q = 0; q < p; ++q) a.r_prev[q] = pl->R[q];
+        a.is_last = last ? 1u : 0u;
+        a.log_s_next = last ? 0u : (log_s - pl->R[p + 1]);
+        a.batch_stride = batch_stride;
+        uint32_t log_c = NTT_TILE_LOG > R ? NTT_TILE_LOG - R : 0;
+        if (last) log_c = p ? std::min(log_c, pl->R[0]) : 0u;
+        else log_c = std::min(log_c, log_s);
+        a.log_c = log_c;
+        const uint32_t tiles = 1u << (log_n - R - log_c);
+        const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
+        const size_t lds_bytes = elems * 32;
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
+        HIP_CHECK(hipGetLastError());
+        log_h += R;
+    }
+}
+
+void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride) {
+    NttPlan* pl = ntt_get_plan(ctx, log_n, flags);
+    ntt_launch(ctx, pl, data_dev, batch, batch_stride);
+}
+
+void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
+                   size_t batch_stride) {
+    NttPlan* pl = get_plan_shift(ctx, log_n, flags, shift);
+    ntt_launch(ctx, pl, data_dev, batch, batch_stride);
+}
+
+}  // namespace plonk
