@@ -237,16 +237,21 @@ def range_proof_circuit(n_bits, x):
     return cs
 
 
-def square_add_circuit(w=3, x=3):
+def square_add_circuit(w=3, x=3, min_gates=16):
     """The w^2 + x = y demo statement (backend/src/circuit.rs:78-113) as a 3-wire
     constraint system: gate 0 mul (w*w = t), gate 1 add (t + x = y), copies
-    a[0]=b[0] and c[0]=a[1].  (dusk-plonk's own 4-wire gates are not in the tree.)"""
+    a[0]=b[0] and c[0]=a[1], padded with dummy gates to n = 16, the size the demo runs at
+    (backend/src/srs.rs:17).  dusk-plonk's own 4-wire gates are not in the tree.  (At n = 4 the
+    reference's 4n-point quotient domain cannot hold t of degree 3n+5, so its own proofs would
+    not verify there.)"""
     cs = ConstraintSystem()
     t = w * w % R_MOD
     g = Gate.mul(); g.a, g.b, g.c = w, w, t; cs.add_gate(g)
     g = Gate.add(); g.a, g.b, g.c = t, x, (t + x) % R_MOD; cs.add_gate(g)
     cs.add_copy_constraint((WIRE_A, 0), (WIRE_B, 0))
     cs.add_copy_constraint((WIRE_C, 0), (WIRE_A, 1))
+    while len(cs.gates) < min_gates:
+        cs.add_gate(Gate.dummy())
     cs.finalize()
     return cs
 

@@ -1,0 +1,423 @@
+"""Host-side mirror of the reference's prover interface over the C ABI.
+
+Names and argument meaning follow backend_new/src: fft.rs (fft / ifft / coset_fft / coset_ifft,
+Domain), kzg.rs (Srs, Commitment::commit), curve.rs (G1Projective::msm), plonk/preprocess.rs
+(preprocess -> ProvingKey) and plonk/prover.rs (Prover::new / prove).  Field elements cross this
+layer as Python ints (canonical value); bulk vectors as numpy uint64 arrays of shape (n, 4)
+holding Montgomery limbs, the in-memory image the C ABI uses.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, PlonkError
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_R = (1 << 256) % R_MOD
+_R_INV = pow(_R, R_MOD - 2, R_MOD)
+_RQ = (1 << 384) % Q_MOD
+_RQ_INV = pow(_RQ, Q_MOD - 2, Q_MOD)
+
+
+def fr_to_array(values):
+    """ints (canonical) -> (n, 4) uint64 Montgomery limbs."""
+    buf = b"".join(((v % R_MOD) * _R % R_MOD).to_bytes(32, "little") for v in values)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+def fr_from_array(arr):
+    """(n, 4) uint64 Montgomery limbs -> list of canonical ints."""
+    b = np.ascontiguousarray(arr, dtype=np.uint64).tobytes()
+    return [int.from_bytes(b[i:i + 32], "little") * _R_INV % R_MOD for i in range(0, len(b), 32)]
+
+
+def _fr_struct(v):
+    s = _lib.Fr()
+    m = (v % R_MOD) * _R % R_MOD
+    for i in range(4):
+        s.l[i] = (m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+    return s
+
+
+def _fr_value(s):
+    return sum(int(s.l[i]) << (64 * i) for i in range(4)) * _R_INV % R_MOD
+
+
+def _g1_struct(pt):
+    g = _lib.G1()
+    if pt is None:
+        g.infinity = 1
+        return g
+    x = pt[0] * _RQ % Q_MOD
+    y = pt[1] * _RQ % Q_MOD
+    for i in range(6):
+        g.x[i] = (x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+        g.y[i] = (y >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+    return g
+
+
+def _g1_value(g):
+    """plonk_g1 -> (x, y) canonical ints, or None for the identity."""
+    if g.infinity:
+        return None
+    x = sum(int(g.x[i]) << (64 * i) for i in range(6)) * _RQ_INV % Q_MOD
+    y = sum(int(g.y[i]) << (64 * i) for i in range(6)) * _RQ_INV % Q_MOD
+    return (x, y)
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def _as_limbs(x, n=None):
+    """Accept a list of ints or an (n, 4) uint64 array; return a contiguous (n, 4) uint64 array."""
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x, dtype=np.uint64)
+        assert a.ndim == 2 and a.shape[1] == 4
+    else:
+        a = fr_to_array(list(x))
+    if n is not None and a.shape[0] != n:
+        raise PlonkError(_lib.PLONK_E_INVALID, "expected %d field elements, got %d" % (n, a.shape[0]))
+    return a
+
+
+class Context:
+    """One HIP device + stream (plonk_ctx)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib.plonk_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_ctx_create(device=%d) failed (no usable HIP device?)" % device)
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise PlonkError(rc, (lib.plonk_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.plonk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.check(lib.plonk_sync(self.h))
+
+    def stream(self):
+        return lib.plonk_ctx_stream(self.h)
+
+    # raw device memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(lib.plonk_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        self.check(lib.plonk_dev_free(self.h, p))
+
+    def upload(self, dev, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(lib.plonk_dev_upload(self.h, dev, _ptr(arr), arr.nbytes))
+
+    def download(self, dev, nbytes):
+        out = np.empty(nbytes // 8, dtype=np.uint64)
+        self.check(lib.plonk_dev_download(self.h, _ptr(out), dev, nbytes))
+        return out
+
+    def ntt(self, data, flags=0, shift=None, batch=1):
+        """In-place NTT of a host (batch*n, 4) uint64 array."""
+        n = data.shape[0] // batch
+        log_n = n.bit_length() - 1
+        if n <= 0 or (1 << log_n) != n:
+            raise PlonkError(_lib.PLONK_E_INVALID, "FFT size must be a power of 2")
+        sh = C.byref(_fr_struct(shift)) if shift is not None else None
+        self.check(lib.plonk_ntt(self.h, _ptr(data), log_n, flags, sh, batch, n))
+        return data
+
+    def ntt_dev(self, dev, log_n, flags=0, shift=None, batch=1, stride=None):
+        sh = C.byref(_fr_struct(shift)) if shift is not None else None
+        self.check(lib.plonk_ntt_dev(self.h, dev, log_n, flags, sh, batch, stride or (1 << log_n)))
+
+    def bench_field_mul(self, which):
+        v = C.c_double()
+        self.check(lib.plonk_bench_field_mul(self.h, which, C.byref(v)))
+        return v.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _pad(coeffs, n):
+    c = list(coeffs)
+    if len(c) > n:
+        raise PlonkError(_lib.PLONK_E_INVALID, "polynomial longer than the domain")
+    return c + [0] * (n - len(c))
+
+
+def _strip(c):
+    while c and c[-1] == 0:
+        c.pop()
+    return c
+
+
+def fft(poly, omega, n, ctx=None):
+    """fft.rs:23 -- evaluations of `poly` (coefficient list) on {omega^i}; omega must be the
+    library's primitive n-th root (Fr::get_root_of_unity(n))."""
+    ctx = ctx or default_context()
+    _check_omega(omega, n)
+    return fr_from_array(ctx.ntt(fr_to_array(_pad(poly, n)), 0))
+
+
+def ifft(evals, omega, ctx=None):
+    """fft.rs:42 -- normalised coefficient list."""
+    ctx = ctx or default_context()
+    _check_omega(omega, len(evals))
+    return _strip(fr_from_array(ctx.ntt(fr_to_array(evals), _lib.NTT_INVERSE)))
+
+
+def coset_fft(poly, omega, k, n, ctx=None):
+    """fft.rs:121."""
+    ctx = ctx or default_context()
+    _check_omega(omega, n)
+    return fr_from_array(ctx.ntt(fr_to_array(_pad(poly, n)), _lib.NTT_COSET, shift=k))
+
+
+def coset_ifft(evals, omega, k, ctx=None):
+    """fft.rs:140 -- n coefficients (zero padded)."""
+    ctx = ctx or default_context()
+    _check_omega(omega, len(evals))
+    return fr_from_array(ctx.ntt(fr_to_array(evals), _lib.NTT_COSET | _lib.NTT_INVERSE, shift=k))
+
+
+_TWO_ADIC_ROOT = pow(7, (R_MOD - 1) >> 32, R_MOD)
+
+
+def root_of_unity(n):
+    """field.rs:167-182."""
+    if n <= 0 or n & (n - 1) or n > (1 << 32):
+        return None
+    return pow(_TWO_ADIC_ROOT, (1 << 32) // n, R_MOD)
+
+
+def _check_omega(omega, n):
+    if n <= 0 or n & (n - 1):
+        raise PlonkError(_lib.PLONK_E_INVALID, "FFT size must be a power of 2")
+    if omega % R_MOD != root_of_unity(n):
+        raise PlonkError(_lib.PLONK_E_INVALID, "omega is not the canonical primitive n-th root of unity")
+
+
+class Domain:
+    """fft.rs:175-249."""
+
+    def __init__(self, n, ctx=None):
+        if n <= 0 or n & (n - 1):
+            raise PlonkError(_lib.PLONK_E_INVALID, "domain size must be a power of 2")
+        self.n = n
+        self.ctx = ctx or default_context()
+        self.omega = root_of_unity(n)
+        self.omega_inv = pow(self.omega, R_MOD - 2, R_MOD)
+        self.n_inv = pow(n, R_MOD - 2, R_MOD)
+
+    def fft(self, poly):
+        return fft(poly, self.omega, self.n, self.ctx)
+
+    def ifft(self, evals):
+        return ifft(evals, self.omega, self.ctx)
+
+    def coset_fft(self, poly, k):
+        return coset_fft(poly, self.omega, k, self.n, self.ctx)
+
+    def coset_ifft(self, evals, k):
+        return coset_ifft(evals, self.omega, k, self.ctx)
+
+
+class Srs:
+    """kzg.rs:26-35 -- g1_powers resident on the device."""
+
+    def __init__(self, handle, ctx):
+        self.h = handle
+        self.ctx = ctx
+
+    @classmethod
+    def from_points(cls, points, ctx=None):
+        """points: list of affine (x, y) ints or None."""
+        ctx = ctx or default_context()
+        arr = (_lib.G1 * len(points))(*[_g1_struct(p) for p in points])
+        h = C.c_void_p()
+        ctx.check(lib.plonk_srs_upload(ctx.h, arr, len(points), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_tau(cls, tau, max_degree, ctx=None):
+        """kzg.rs:71-94 -- [tau^i]_1 for i = 0..=max_degree, generated on the device."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        t = _fr_struct(tau)
+        ctx.check(lib.plonk_srs_from_tau(ctx.h, C.byref(t), max_degree + 1, C.byref(h)))
+        return cls(h, ctx)
+
+    def __len__(self):
+        return lib.plonk_srs_len(self.h)
+
+    @property
+    def max_degree(self):
+        return len(self) - 1
+
+    def g1_powers(self, first=0, count=None):
+        count = len(self) - first if count is None else count
+        arr = (_lib.G1 * count)()
+        self.ctx.check(lib.plonk_srs_download(self.ctx.h, self.h, first, count, arr))
+        return [_g1_value(g) for g in arr]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.plonk_srs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Commitment:
+    """kzg.rs:229-245."""
+
+    def __init__(self, point):
+        self.point = point
+
+    @staticmethod
+    def commit(poly, srs):
+        a = _as_limbs(poly)
+        out = _lib.G1()
+        srs.ctx.check(lib.plonk_commit(srs.ctx.h, srs.h, _ptr(a), a.shape[0], C.byref(out)))
+        return Commitment(_g1_value(out))
+
+
+def msm(points, scalars, ctx=None):
+    """curve.rs:169-173 -- sum scalars[i] * points[i]; returns the affine point (or None)."""
+    ctx = ctx or default_context()
+    n = min(len(points), len(scalars))
+    arr = (_lib.G1 * max(n, 1))(*[_g1_struct(p) for p in points[:n]])
+    sc = _as_limbs(scalars[:n]) if n else np.zeros((1, 4), dtype=np.uint64)
+    out = _lib.G1()
+    ctx.check(lib.plonk_msm(ctx.h, arr, _ptr(sc), n, C.byref(out)))
+    return _g1_value(out)
+
+
+PROOF_G1 = ("a_comm", "b_comm", "c_comm", "z_comm", "t_lo_comm", "t_mid_comm", "t_hi_comm",
+            "w_zeta_comm", "w_zeta_omega_comm")
+PROOF_FR = ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval")
+
+
+class Proof:
+    """plonk/types.rs:74-114."""
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def to_dict(self):
+        d = {k: _g1_value(getattr(self.raw, k)) for k in PROOF_G1}
+        d.update({k: _fr_value(getattr(self.raw, k)) for k in PROOF_FR})
+        return d
+
+    def to_bytes(self):
+        out = (C.c_uint8 * _lib.PROOF_WIRE_BYTES)()
+        rc = lib.plonk_proof_serialize(C.byref(self.raw), out)
+        if rc != 0:
+            raise PlonkError(rc, "plonk_proof_serialize")
+        return bytes(out)
+
+    def challenges(self, public_inputs=()):
+        """beta, gamma, alpha, zeta, v, u re-derived from the proof (verifier.rs:51-92)."""
+        pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])
+        out = (_lib.Fr * 6)()
+        rc = lib.plonk_proof_challenges(C.byref(self.raw), pis, len(public_inputs), out)
+        if rc != 0:
+            raise PlonkError(rc, "plonk_proof_challenges")
+        return [_fr_value(x) for x in out]
+
+
+class ProvingKey:
+    """plonk/preprocess.rs:104-186 + plonk/types.rs:12 -- built on the device from the selector and
+    S_sigma evaluation vectors."""
+
+    def __init__(self, n, selectors, sigmas, k1, k2, public_input_positions=(), ctx=None):
+        ctx = ctx or default_context()
+        log_n = n.bit_length() - 1
+        if n <= 0 or (1 << log_n) != n:
+            raise PlonkError(_lib.PLONK_E_INVALID, "n must be a power of 2")
+        arrs = [_as_limbs(v, n) for v in list(selectors) + list(sigmas)]
+        pos = np.asarray(list(public_input_positions), dtype=np.uint32)
+        h = C.c_void_p()
+        k1s, k2s = _fr_struct(k1), _fr_struct(k2)
+        ctx.check(lib.plonk_pk_create(ctx.h, log_n, *[_ptr(a) for a in arrs], C.byref(k1s), C.byref(k2s),
+                                      _ptr(pos) if len(pos) else None, len(pos), C.byref(h)))
+        self.h, self.ctx, self.n = h, ctx, n
+        self.k1, self.k2 = k1, k2
+        self.omega = root_of_unity(n)
+
+    def commitments(self, srs):
+        """The eight verification-key commitments (preprocess.rs:130-138)."""
+        out = (_lib.G1 * 8)()
+        self.ctx.check(lib.plonk_pk_commitments(self.ctx.h, self.h, srs.h, out))
+        return [_g1_value(g) for g in out]
+
+    def poly(self, which):
+        out = np.empty((self.n, 4), dtype=np.uint64)
+        ln = C.c_size_t()
+        self.ctx.check(lib.plonk_pk_poly(self.ctx.h, self.h, which, _ptr(out), C.byref(ln)))
+        return fr_from_array(out[:ln.value])
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.plonk_pk_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Prover:
+    """plonk/prover.rs:24-62 -- Prover::new(cs, pk, permutation, domain, srs) / prove(public_inputs).
+    `wires` = ConstraintSystem::get_wire_values(): three length-n vectors.  The reference draws its
+    eleven blinding scalars from thread_rng (prover.rs:189-194, 310-312, 537-538); here the caller
+    passes them (`blinding`), or they come from os.urandom."""
+
+    def __init__(self, wires, pk, srs):
+        self.pk, self.srs = pk, srs
+        self.wires = [_as_limbs(w, pk.n) for w in wires]
+
+    def prove(self, public_inputs=(), blinding=None):
+        import os
+        if blinding is None:
+            blinding = [int.from_bytes(os.urandom(40), "little") % R_MOD for _ in range(11)]
+        if len(blinding) != 11:
+            raise PlonkError(_lib.PLONK_E_INVALID, "blinding must hold 11 scalars")
+        bl = (_lib.Fr * 11)(*[_fr_struct(b) for b in blinding])
+        pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])
+        raw = _lib.Proof()
+        ctx = self.pk.ctx
+        ctx.check(lib.plonk_prove_3wire(ctx.h, self.pk.h, self.srs.h, _ptr(self.wires[0]), _ptr(self.wires[1]),
+                                        _ptr(self.wires[2]), pis, len(public_inputs), bl, C.byref(raw)))
+        return Proof(raw)

@@ -3,6 +3,8 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "msm.hpp"
+#include "prover.hpp"
 
 namespace plonk {
 double bench_field_mul(Ctx* ctx, uint32_t which);
@@ -14,6 +16,12 @@ using namespace plonk;
 
 struct plonk_ctx {
     Ctx c;
+};
+struct plonk_srs {
+    Srs s;
+};
+struct plonk_pk {
+    Pk k;
 };
 
 #define API_BEGIN(ctxp) \
@@ -144,6 +152,181 @@ int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t 
     HIP_CHECK(hipMemcpyAsync(data_host, buf.p, total * sizeof(fr_t), hipMemcpyDeviceToHost, C_->stream));
     HIP_CHECK(hipStreamSynchronize(C_->stream));
     API_END()
+}
+
+
+// ---- SRS / commit / MSM ----
+static host::fr_h fr_in(const plonk_fr* x, const char* what) {
+    PLONK_REQUIRE(x != nullptr, std::string(what) + ": null");
+    host::fr_h h;
+    memcpy(h.l, x->l, 32);
+    PLONK_REQUIRE(!host::Fr::geq_p(h), std::string(what) + ": not a reduced Fr");
+    return h;
+}
+
+int32_t plonk_srs_upload(plonk_ctx* ctx, const plonk_g1* g1_powers, size_t n, plonk_srs** out) {
+    if (!ctx || !out || (n && !g1_powers)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    *out = reinterpret_cast<plonk_srs*>(srs_upload(C_, g1_powers, n));
+    API_END()
+}
+
+int32_t plonk_srs_from_tau(plonk_ctx* ctx, const plonk_fr* tau, size_t n, plonk_srs** out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    *out = reinterpret_cast<plonk_srs*>(srs_from_tau(C_, fr_in(tau, "srs tau"), n));
+    API_END()
+}
+
+size_t plonk_srs_len(const plonk_srs* srs) { return srs ? reinterpret_cast<const Srs*>(srs)->n : 0; }
+
+int32_t plonk_srs_download(plonk_ctx* ctx, const plonk_srs* srs, size_t first, size_t count, plonk_g1* out) {
+    if (!ctx || !srs || (count && !out)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(first <= s->n && count <= s->n - first, "srs: range out of bounds");
+    std::vector<g1_affine_t> tmp(count);
+    if (count) HIP_CHECK(hipMemcpy(tmp.data(), s->points.p + first, count * sizeof(g1_affine_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < count; ++i) g1_unpack(tmp[i], out + i);
+    API_END()
+}
+
+void plonk_srs_free(plonk_srs* srs) {
+    if (!srs) return;
+    Srs* s = reinterpret_cast<Srs*>(srs);
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    delete s;
+}
+
+int32_t plonk_commit_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_dev, size_t len, plonk_g1* out) {
+    if (!ctx || !srs || !out || (len && !coeffs_dev)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(s->device == C_->device, "commit: SRS lives on another device");
+    g1_from_host(commit_checked(C_, s, reinterpret_cast<const fr_t*>(coeffs_dev), len), out);
+    API_END()
+}
+
+int32_t plonk_commit(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_host, size_t len, plonk_g1* out) {
+    if (!ctx || !srs || !out || (len && !coeffs_host)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(s->device == C_->device, "commit: SRS lives on another device");
+    // Polynomial::from_coeffs normalises (polynomial.rs:47-51): trailing zeros do not count
+    // towards the degree that kzg.rs:232 checks.
+    while (len && (coeffs_host[len - 1].l[0] | coeffs_host[len - 1].l[1] | coeffs_host[len - 1].l[2] |
+                   coeffs_host[len - 1].l[3]) == 0)
+        --len;
+    PLONK_REQUIRE(len <= s->n, "commit: polynomial degree exceeds SRS max degree");
+    DevBuf<fr_t> buf(len);
+    if (len) HIP_CHECK(hipMemcpyAsync(buf.p, coeffs_host, len * sizeof(fr_t), hipMemcpyHostToDevice, C_->stream));
+    g1_from_host(msm_run(C_, s->points.p, buf.p, len), out);
+    API_END()
+}
+
+int32_t plonk_msm(plonk_ctx* ctx, const plonk_g1* points_host, const plonk_fr* scalars_host, size_t n, plonk_g1* out) {
+    if (!ctx || !out || (n && (!points_host || !scalars_host))) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    std::unique_ptr<Srs> tmp(srs_upload(C_, points_host, n));
+    DevBuf<fr_t> sc(n);
+    if (n) HIP_CHECK(hipMemcpyAsync(sc.p, scalars_host, n * sizeof(fr_t), hipMemcpyHostToDevice, C_->stream));
+    g1_from_host(msm_run(C_, tmp->points.p, sc.p, n), out);
+    API_END()
+}
+
+// ---- proving key ----
+int32_t plonk_pk_create(plonk_ctx* ctx, uint32_t log_n, const plonk_fr* q_m, const plonk_fr* q_l, const plonk_fr* q_r,
+                        const plonk_fr* q_o, const plonk_fr* q_c, const plonk_fr* s_sigma1, const plonk_fr* s_sigma2,
+                        const plonk_fr* s_sigma3, const plonk_fr* k1, const plonk_fr* k2, const uint32_t* pi_positions,
+                        size_t n_pi_positions, plonk_pk** out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    const plonk_fr* sel[5] = {q_m, q_l, q_r, q_o, q_c};
+    const plonk_fr* sig[3] = {s_sigma1, s_sigma2, s_sigma3};
+    for (auto p : sel) PLONK_REQUIRE(p != nullptr, "pk: null selector vector");
+    for (auto p : sig) PLONK_REQUIRE(p != nullptr, "pk: null sigma vector");
+    PLONK_REQUIRE(n_pi_positions == 0 || pi_positions != nullptr, "pk: null public input positions");
+    *out = reinterpret_cast<plonk_pk*>(pk_create(C_, log_n, sel, sig, fr_in(k1, "pk k1"), fr_in(k2, "pk k2"), pi_positions,
+                                                 n_pi_positions));
+    API_END()
+}
+
+void plonk_pk_free(plonk_pk* pk) {
+    if (!pk) return;
+    Pk* k = reinterpret_cast<Pk*>(pk);
+    (void)hipSetDevice(k->device);
+    (void)hipDeviceSynchronize();
+    delete k;
+}
+
+int32_t plonk_pk_commitments(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, plonk_g1 out[8]) {
+    if (!ctx || !pk || !srs || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    for (int q = 0; q < 8; ++q) g1_from_host(commit_checked(C_, s, k->coef.p + q * k->n, k->n), out + q);
+    API_END()
+}
+
+int32_t plonk_pk_poly(plonk_ctx* ctx, const plonk_pk* pk, uint32_t which, plonk_fr* out_host, size_t* len) {
+    if (!ctx || !pk || !out_host || !len || which > 8) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    HIP_CHECK(hipMemcpy(out_host, k->coef.p + which * k->n, k->n * sizeof(fr_t), hipMemcpyDeviceToHost));
+    size_t l = k->n;
+    while (l && (out_host[l - 1].l[0] | out_host[l - 1].l[1] | out_host[l - 1].l[2] | out_host[l - 1].l[3]) == 0) --l;
+    *len = l;
+    API_END()
+}
+
+int32_t plonk_quotient_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, plonk_fr* a_dev, plonk_fr* b_dev, plonk_fr* c_dev,
+                                 plonk_fr* z_dev, plonk_fr* pi_dev, const plonk_fr* alpha, const plonk_fr* beta,
+                                 const plonk_fr* gamma, plonk_fr* t_out_dev) {
+    if (!ctx || !pk || !a_dev || !b_dev || !c_dev || !z_dev || !t_out_dev) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    PLONK_REQUIRE(k->device == C_->device, "quotient: proving key lives on another device");
+    quotient_3wire(C_, k, reinterpret_cast<fr_t*>(a_dev), reinterpret_cast<fr_t*>(b_dev), reinterpret_cast<fr_t*>(c_dev),
+                   reinterpret_cast<fr_t*>(z_dev), reinterpret_cast<fr_t*>(pi_dev), fr_in(alpha, "alpha"),
+                   fr_in(beta, "beta"), fr_in(gamma, "gamma"), reinterpret_cast<fr_t*>(t_out_dev));
+    API_END()
+}
+
+int32_t plonk_prove_3wire(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, const plonk_fr* a_evals,
+                          const plonk_fr* b_evals, const plonk_fr* c_evals, const plonk_fr* public_inputs,
+                          size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out) {
+    if (!ctx || !pk || !srs || !a_evals || !b_evals || !c_evals || !blinding || !out) return PLONK_E_INVALID;
+    if (n_public_inputs && !public_inputs) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
+    prove_3wire(C_, k, s, a_evals, b_evals, c_evals, public_inputs, n_public_inputs, blinding, out);
+    API_END()
+}
+
+int32_t plonk_proof_serialize(const plonk_proof* proof, uint8_t out[PLONK_PROOF_WIRE_BYTES]) {
+    if (!proof || !out) return PLONK_E_INVALID;
+    const plonk_g1* g[9] = {&proof->a_comm, &proof->b_comm, &proof->c_comm, &proof->z_comm, &proof->t_lo_comm,
+                            &proof->t_mid_comm, &proof->t_hi_comm, &proof->w_zeta_comm, &proof->w_zeta_omega_comm};
+    const plonk_fr* f[6] = {&proof->a_eval, &proof->b_eval, &proof->c_eval, &proof->s_sigma1_eval,
+                            &proof->s_sigma2_eval, &proof->z_omega_eval};
+    uint8_t* p = out;
+    for (int k = 0; k < 7; ++k, p += 48) plonk_g1_compress(g[k], p);
+    for (int k = 0; k < 6; ++k, p += 32) plonk_fr_to_bytes(f[k], p);
+    for (int k = 7; k < 9; ++k, p += 48) plonk_g1_compress(g[k], p);
+    return PLONK_OK;
+}
+
+int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_inputs, size_t n_public_inputs,
+                               plonk_fr out[6]) {
+    if (!proof || !out || (n_public_inputs && !public_inputs)) return PLONK_E_INVALID;
+    proof_challenges(proof, public_inputs, n_public_inputs, out);
+    return PLONK_OK;
 }
 
 int32_t plonk_fr_to_bytes(const plonk_fr* a, uint8_t out[32]) {

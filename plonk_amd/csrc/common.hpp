@@ -65,6 +65,8 @@ struct Ctx {
     std::string last_error;
     std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9
     DevBuf<fr_t> ntt_tmp;                                  // intermediate image of a multi-pass NTT
+    std::shared_ptr<void> msm_ws;                          // MsmWorkspace (msm.hip)
+    std::shared_ptr<void> prover_ws;                       // ProverWorkspace (prover.hip)
     ~Ctx();
 };
 

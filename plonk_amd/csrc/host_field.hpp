@@ -237,5 +237,113 @@ inline void g1_compress(const G1AffineH& p, uint8_t out[48]) {
     if (larger) out[0] |= 0x20;
 }
 
+
+// ---- G1 in XYZZ coordinates on the host (window combination, conversion to affine) ----
+struct G1XyzzH {
+    fq_h x, y, zz, zzz;  // zz == 0: identity
+};
+
+inline G1XyzzH g1_identity() {
+    G1XyzzH r;
+    r.x = Fq::zero(); r.y = Fq::zero(); r.zz = Fq::zero(); r.zzz = Fq::zero();
+    return r;
+}
+inline bool g1_is_inf(const G1XyzzH& p) { return Fq::is_zero(p.zz); }
+
+inline G1XyzzH g1_from_affine(const G1AffineH& a) {
+    if (a.inf) return g1_identity();
+    G1XyzzH r;
+    r.x = a.x; r.y = a.y; r.zz = Fq::one(); r.zzz = Fq::one();
+    return r;
+}
+
+inline G1XyzzH g1_double(const G1XyzzH& p) {
+    if (g1_is_inf(p) || Fq::is_zero(p.y)) return g1_identity();
+    G1XyzzH r;
+    fq_h U = Fq::add(p.y, p.y);
+    fq_h V = Fq::sqr(U);
+    fq_h W = Fq::mul(U, V);
+    fq_h S = Fq::mul(p.x, V);
+    fq_h xx = Fq::sqr(p.x);
+    fq_h M = Fq::add(Fq::add(xx, xx), xx);
+    r.x = Fq::sub(Fq::sqr(M), Fq::add(S, S));
+    r.y = Fq::sub(Fq::mul(M, Fq::sub(S, r.x)), Fq::mul(W, p.y));
+    r.zz = Fq::mul(V, p.zz);
+    r.zzz = Fq::mul(W, p.zzz);
+    return r;
+}
+
+inline G1XyzzH g1_add(const G1XyzzH& a, const G1XyzzH& b) {
+    if (g1_is_inf(b)) return a;
+    if (g1_is_inf(a)) return b;
+    fq_h U1 = Fq::mul(a.x, b.zz), U2 = Fq::mul(b.x, a.zz);
+    fq_h S1 = Fq::mul(a.y, b.zzz), S2 = Fq::mul(b.y, a.zzz);
+    fq_h P = Fq::sub(U2, U1), R = Fq::sub(S2, S1);
+    if (Fq::is_zero(P)) return Fq::is_zero(R) ? g1_double(a) : g1_identity();
+    fq_h PP = Fq::sqr(P), PPP = Fq::mul(P, PP), Q = Fq::mul(U1, PP);
+    G1XyzzH r;
+    r.x = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::add(Q, Q));
+    r.y = Fq::sub(Fq::mul(R, Fq::sub(Q, r.x)), Fq::mul(S1, PPP));
+    r.zz = Fq::mul(Fq::mul(a.zz, b.zz), PP);
+    r.zzz = Fq::mul(Fq::mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
+inline G1XyzzH g1_neg(const G1XyzzH& p) {
+    G1XyzzH r = p;
+    r.y = Fq::neg(p.y);
+    return r;
+}
+
+inline G1AffineH g1_to_affine(const G1XyzzH& p) {
+    G1AffineH a;
+    if (g1_is_inf(p)) {
+        a.x = Fq::zero(); a.y = Fq::zero(); a.inf = true;
+        return a;
+    }
+    // 1/ZZ = ZZ^2 * (1/ZZZ)^2 ... use two inversions' worth via one: inv(ZZ*ZZZ)
+    fq_h t = Fq::inv(Fq::mul(p.zz, p.zzz));
+    fq_h zz_inv = Fq::mul(t, p.zzz);
+    fq_h zzz_inv = Fq::mul(t, p.zz);
+    a.x = Fq::mul(p.x, zz_inv);
+    a.y = Fq::mul(p.y, zzz_inv);
+    a.inf = false;
+    return a;
+}
+
+// scalar given as canonical little-endian limbs
+inline G1XyzzH g1_mul_limbs(const G1XyzzH& p, const uint64_t* e, int nl) {
+    G1XyzzH r = g1_identity();
+    for (int i = nl * 64 - 1; i >= 0; --i) {
+        r = g1_double(r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = g1_add(r, p);
+    }
+    return r;
+}
+
+inline G1AffineH g1_generator() {
+    // canonical coordinates of the BLS12-381 G1 generator (ark_bls12_381::G1Affine::generator,
+    // curve.rs:64)
+    static const uint64_t GX[6] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull,
+                                   0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull};
+    static const uint64_t GY[6] = {0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull,
+                                   0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+    G1AffineH g;
+    fq_h x, y;
+    memcpy(x.l, GX, 48);
+    memcpy(y.l, GY, 48);
+    g.x = Fq::to_mont(x);
+    g.y = Fq::to_mont(y);
+    g.inf = false;
+    return g;
+}
+
+inline bool g1_on_curve(const G1AffineH& a) {
+    if (a.inf) return true;
+    fq_h lhs = Fq::sqr(a.y);
+    fq_h rhs = Fq::add(Fq::mul(Fq::sqr(a.x), a.x), Fq::from_u64(4));
+    return lhs == rhs;
+}
+
 }  // namespace host
 }  // namespace plonk

@@ -186,6 +186,8 @@ struct NttPlan {
 
 Ctx::~Ctx() {
     plans.clear();
+    msm_ws.reset();
+    prover_ws.reset();
     ntt_tmp.release();
     if (stream) (void)hipStreamDestroy(stream);
 }

@@ -1,0 +1,462 @@
+// Proving key, fused round-3 quotient kernel and the 5-round prover shell.
+//
+// Replaces preprocess (backend_new/src/plonk/preprocess.rs:104-186), the round-3 body
+// (plonk/prover.rs:364-457, :497) and Prover::prove (plonk/prover.rs:56-149).  Every bulk vector
+// stays in HBM from the witness upload to the last commitment; the host sees only commitments,
+// six evaluations and the transcript.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+#include "msm.hpp"
+#include "poly.hpp"
+#include "prover.hpp"
+#include "transcript.hpp"
+
+namespace plonk {
+
+using host::Fr;
+using host::fr_h;
+
+// ---- fused quotient evaluation over the 4n coset points (prover.rs:415-457) ----
+struct QuotientArgs {
+    const fr_t *a, *b, *c, *z, *pi;   // coset evaluations, 4n each (pi nullable)
+    const fr_t* pk_ext;               // [9][4n]: q_m q_l q_r q_o q_c s1 s2 s3 l1
+    const fr_t *x_lo, *x_hi;          // x_i = x_lo[i & mask] * x_hi[i >> log_l] = 7 * w_4n^i
+    fr_t* t;
+    fr_t alpha, alpha2, beta, gamma, beta_k1, beta_k2;
+    fr_t zh_inv[4];                   // 1 / (x_i^n - 1) depends on i mod 4 only
+    uint32_t n4, log_l;
+};
+
+__global__ __launch_bounds__(256) void quotient_kernel(QuotientArgs q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.n4) return;
+    const size_t N = q.n4;
+    const fr_t a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), z = ld(q.z + i);
+    const fr_t zw = ld(q.z + ((i + 4) & (q.n4 - 1)));  // z(w X) on the 4n coset is a rotation by 4
+    fr_t x = ld(q.x_lo + (i & ((1u << q.log_l) - 1u)));
+    if (i >> q.log_l) x = fr_mul(x, ld(q.x_hi + (i >> q.log_l)));
+    // gate: q_M a b + q_L a + q_R b + q_O c + q_C + PI
+    fr_t gate = fr_mul(fr_mul(ld(q.pk_ext + i), a), b);
+    gate = fr_add(gate, fr_mul(ld(q.pk_ext + N + i), a));
+    gate = fr_add(gate, fr_mul(ld(q.pk_ext + 2 * N + i), b));
+    gate = fr_add(gate, fr_mul(ld(q.pk_ext + 3 * N + i), c));
+    gate = fr_add(gate, ld(q.pk_ext + 4 * N + i));
+    if (q.pi) gate = fr_add(gate, ld(q.pi + i));
+    // permutation
+    const fr_t ag = fr_add(a, q.gamma), bg = fr_add(b, q.gamma), cg = fr_add(c, q.gamma);
+    fr_t num = fr_mul(z, fr_add(ag, fr_mul(q.beta, x)));
+    num = fr_mul(num, fr_add(bg, fr_mul(q.beta_k1, x)));
+    num = fr_mul(num, fr_add(cg, fr_mul(q.beta_k2, x)));
+    fr_t den = fr_mul(zw, fr_add(ag, fr_mul(q.beta, ld(q.pk_ext + 5 * N + i))));
+    den = fr_mul(den, fr_add(bg, fr_mul(q.beta, ld(q.pk_ext + 6 * N + i))));
+    den = fr_mul(den, fr_add(cg, fr_mul(q.beta, ld(q.pk_ext + 7 * N + i))));
+    const fr_t perm = fr_sub(num, den);
+    const fr_t l1c = fr_mul(ld(q.pk_ext + 8 * N + i), fr_sub(z, f_one<FrP>()));
+    fr_t numer = fr_add(gate, fr_add(fr_mul(q.alpha, perm), fr_mul(q.alpha2, l1c)));
+    const uint32_t r = i & 3u;
+    const fr_t zi = r == 0 ? q.zh_inv[0] : (r == 1 ? q.zh_inv[1] : (r == 2 ? q.zh_inv[2] : q.zh_inv[3]));
+    st(q.t + i, fr_mul(numer, zi));
+}
+
+static std::vector<fr_h> host_powers(const fr_h& first, const fr_h& base, size_t count) {
+    std::vector<fr_h> v(count);
+    fr_h acc = first;
+    for (size_t i = 0; i < count; ++i) {
+        v[i] = acc;
+        acc = Fr::mul(acc, base);
+    }
+    return v;
+}
+
+static void upload_fr(DevBuf<fr_t>& buf, const std::vector<fr_h>& v) {
+    buf.alloc(v.size());
+    HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+}
+
+Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const fr_h& k1,
+              const fr_h& k2, const uint32_t* pi_pos, size_t n_pi_pos) {
+    PLONK_REQUIRE(log_n >= 2 && log_n <= 28, "pk: domain size must be 2^2 .. 2^28");
+    std::unique_ptr<Pk> pk(new Pk());
+    const size_t n = (size_t)1 << log_n, n4 = 4 * n;
+    pk->device = ctx->device;
+    pk->log_n = log_n;
+    pk->n = n;
+    pk->k1 = k1;
+    pk->k2 = k2;
+    pk->omega = host::fr_root_of_unity(log_n);
+    for (size_t i = 0; i < n_pi_pos; ++i) {
+        PLONK_REQUIRE(pi_pos[i] < n, "pk: public input position out of range");
+        pk->pi_positions.push_back(pi_pos[i]);
+    }
+    pk->coef.alloc(9 * n);
+    pk->ext.alloc(9 * n4);
+    pk->sig_ev.alloc(3 * n);
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < 5; ++k)
+        HIP_CHECK(hipMemcpyAsync(pk->coef.p + k * n, sel[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+    for (int k = 0; k < 3; ++k) {
+        HIP_CHECK(hipMemcpyAsync(pk->coef.p + (5 + k) * n, sig[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(pk->sig_ev.p + k * n, sig[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+    }
+    // L1 evaluations: e_0 (preprocess.rs:142)
+    HIP_CHECK(hipMemsetAsync(pk->coef.p + 8 * n, 0, n * sizeof(fr_t), st));
+    const fr_h one = Fr::one();
+    HIP_CHECK(hipMemcpyAsync(pk->coef.p + 8 * n, &one, sizeof(fr_t), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    // evaluations -> coefficients (preprocess.rs:115-127)
+    ntt_run(ctx, pk->coef.p, log_n, NTT_INVERSE, 9, n);
+    // coefficients -> evaluations on the 4n coset 7*H (what prover.rs:380-392 does per proof)
+    HIP_CHECK(hipMemsetAsync(pk->ext.p, 0, 9 * n4 * sizeof(fr_t), st));
+    HIP_CHECK(hipMemcpy2DAsync(pk->ext.p, n4 * sizeof(fr_t), pk->coef.p, n * sizeof(fr_t), n * sizeof(fr_t), 9,
+                               hipMemcpyDeviceToDevice, st));
+    ntt_run(ctx, pk->ext.p, log_n + 2, NTT_COSET, 9, n4);
+    // two-level tables: w^i (domain n) and x_i = 7 w_4n^i
+    pk->log_lw = (log_n + 1) / 2;
+    upload_fr(pk->w_lo, host_powers(Fr::one(), pk->omega, (size_t)1 << pk->log_lw));
+    upload_fr(pk->w_hi, host_powers(Fr::one(), Fr::pow_u64(pk->omega, (uint64_t)1 << pk->log_lw),
+                                    (size_t)1 << (log_n - pk->log_lw)));
+    const fr_h w4 = host::fr_root_of_unity(log_n + 2);
+    const fr_h g = Fr::from_u64(7);
+    pk->log_lx = (log_n + 3) / 2;
+    upload_fr(pk->x_lo, host_powers(g, w4, (size_t)1 << pk->log_lx));
+    upload_fr(pk->x_hi, host_powers(Fr::one(), Fr::pow_u64(w4, (uint64_t)1 << pk->log_lx),
+                                    (size_t)1 << (log_n + 2 - pk->log_lx)));
+    // Z_H(7 w_4n^i) = 7^n * w_4^(i mod 4) - 1   (prover.rs:400-405)
+    const fr_h gn = Fr::pow_u64(g, n);
+    const fr_h i4 = Fr::pow_u64(w4, n);  // primitive 4th root of unity
+    fr_h cur = gn;
+    for (int r = 0; r < 4; ++r) {
+        const fr_h zh = Fr::sub(cur, Fr::one());
+        PLONK_REQUIRE(!Fr::is_zero(zh), "pk: Z_H vanishes on the coset");
+        pk->zh_inv[r] = Fr::inv(zh);
+        cur = Fr::mul(cur, i4);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    return pk.release();
+}
+
+void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr_t* pi, const fr_h& alpha, const fr_h& beta,
+                  const fr_h& gamma, fr_t* t_out) {
+    const uint32_t n4 = (uint32_t)(4 * pk->n);
+    QuotientArgs q;
+    q.a = a; q.b = b; q.c = c; q.z = z; q.pi = pi;
+    q.pk_ext = pk->ext.p;
+    q.x_lo = pk->x_lo.p; q.x_hi = pk->x_hi.p;
+    q.t = t_out;
+    q.alpha = to_dev(alpha);
+    q.alpha2 = to_dev(Fr::mul(alpha, alpha));
+    q.beta = to_dev(beta);
+    q.gamma = to_dev(gamma);
+    q.beta_k1 = to_dev(Fr::mul(beta, pk->k1));
+    q.beta_k2 = to_dev(Fr::mul(beta, pk->k2));
+    for (int r = 0; r < 4; ++r) q.zh_inv[r] = to_dev(pk->zh_inv[r]);
+    q.n4 = n4;
+    q.log_l = pk->log_lx;
+    hipLaunchKernelGGL(quotient_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, q);
+    HIP_CHECK(hipGetLastError());
+}
+
+// plonk_quotient_3wire_dev: coset NTTs of the wire polynomials, fused evaluation, coset iNTT.
+void quotient_3wire(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr_t* pi, const fr_h& alpha,
+                    const fr_h& beta, const fr_h& gamma, fr_t* t_out) {
+    const uint32_t log4 = pk->log_n + 2;
+    ntt_run(ctx, a, log4, NTT_COSET, 1, 0);
+    ntt_run(ctx, b, log4, NTT_COSET, 1, 0);
+    ntt_run(ctx, c, log4, NTT_COSET, 1, 0);
+    ntt_run(ctx, z, log4, NTT_COSET, 1, 0);
+    if (pi) ntt_run(ctx, pi, log4, NTT_COSET, 1, 0);
+    quotient_run(ctx, pk, a, b, c, z, pi, alpha, beta, gamma, t_out);
+    ntt_run(ctx, t_out, log4, NTT_COSET | NTT_INVERSE, 1, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+struct ProverWorkspace {
+    DevBuf<fr_t> w4;      // [5][4n]  a b c z pi: coefficients, then coset evaluations
+    DevBuf<fr_t> t;       // [4n]
+    DevBuf<fr_t> ev;      // [3][n]   wire evaluations
+    DevBuf<fr_t> co;      // [4][n+8] blinded coefficient vectors a b c z
+    DevBuf<fr_t> num, den, scr;  // [n]
+    DevBuf<fr_t> tp;      // [3][n+8] t_lo t_mid t_hi (blinded)
+    DevBuf<fr_t> wnum, wq, tmp;  // [n+8]
+    DevBuf<fr_t> evals;   // [8]
+    DevBuf<fr_t> totals, partial;
+    DevBuf<uint32_t> flag;
+};
+
+static ProverWorkspace* prover_workspace(Ctx* ctx) {
+    if (!ctx->prover_ws)
+        ctx->prover_ws = std::shared_ptr<void>(new ProverWorkspace(), [](void* p) { delete static_cast<ProverWorkspace*>(p); });
+    return static_cast<ProverWorkspace*>(ctx->prover_ws.get());
+}
+
+static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev) {
+    // kzg.rs:231-245.  Coefficients past the SRS must be zero (the reference strips trailing zeros
+    // before its length check and panics otherwise).
+    size_t m = std::min(len, srs->n);
+    if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
+    return msm_run(ctx, srs->points.p, coeffs, m);
+}
+
+host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
+    ProverWorkspace* ws = prover_workspace(ctx);
+    ws->flag.ensure(4);
+    HIP_CHECK(hipMemsetAsync(ws->flag.p, 0, 16, ctx->stream));
+    host::G1AffineH r = commit_dev(ctx, srs, coeffs_dev, len, ws->flag.p);
+    uint32_t f = 0;
+    HIP_CHECK(hipMemcpy(&f, ws->flag.p, 4, hipMemcpyDeviceToHost));
+    PLONK_REQUIRE(f == 0, "commit: polynomial degree exceeds SRS max degree");
+    return r;
+}
+
+static void check_flag(Ctx* ctx, ProverWorkspace* ws) {
+    uint32_t f = 0;
+    HIP_CHECK(hipMemcpyAsync(&f, ws->flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PLONK_REQUIRE(!(f & 1u), "prove: zero denominator in the permutation accumulator");
+    PLONK_REQUIRE(!(f & 2u), "prove: polynomial degree exceeds its bound (t above 3n+5, or a commitment above the SRS)");
+}
+
+void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
+                 const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out) {
+    const size_t n = pk->n, n4 = 4 * n, ns = n + 8;
+    const uint32_t log_n = pk->log_n;
+    PLONK_REQUIRE(srs->n >= 1, "prove: empty SRS");
+    ProverWorkspace* ws = prover_workspace(ctx);
+    ws->w4.ensure(5 * n4); ws->t.ensure(n4); ws->ev.ensure(3 * n); ws->co.ensure(4 * ns);
+    ws->num.ensure(n); ws->den.ensure(n); ws->scr.ensure(n); ws->tp.ensure(3 * ns);
+    ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
+    hipStream_t st = ctx->stream;
+    fr_h bl[11];
+    for (int i = 0; i < 11; ++i) {
+        memcpy(bl[i].l, blinding[i].l, 32);
+        PLONK_REQUIRE(!Fr::geq_p(bl[i]), "prove: blinding scalar not reduced");
+    }
+    std::vector<fr_h> pi(n_pub);
+    for (size_t i = 0; i < n_pub; ++i) {
+        memcpy(pi[i].l, pub[i].l, 32);
+        PLONK_REQUIRE(!Fr::geq_p(pi[i]), "prove: public input not reduced");
+    }
+    fr_t* W[5];
+    for (int k = 0; k < 5; ++k) W[k] = ws->w4.p + k * n4;
+    fr_t* CO[4];
+    for (int k = 0; k < 4; ++k) CO[k] = ws->co.p + k * ns;
+    fr_t* TP[3];
+    for (int k = 0; k < 3; ++k) TP[k] = ws->tp.p + k * ns;
+
+    host::Transcript tr("PLONK-v1");  // prover.rs:64
+    for (size_t i = 0; i < n_pub; ++i) tr.absorb_fr("pi_" + std::to_string(i), pi[i]);  // :69-71
+
+    HIP_CHECK(hipMemsetAsync(ws->flag.p, 0, 16, st));
+    HIP_CHECK(hipMemsetAsync(ws->w4.p, 0, 5 * n4 * sizeof(fr_t), st));
+    HIP_CHECK(hipMemsetAsync(ws->co.p, 0, 4 * ns * sizeof(fr_t), st));
+    HIP_CHECK(hipMemsetAsync(ws->tp.p, 0, 3 * ns * sizeof(fr_t), st));
+
+    // ---- round 1 (prover.rs:181-244) ----
+    const plonk_fr* evs[3] = {a_ev, b_ev, c_ev};
+    for (int k = 0; k < 3; ++k) {
+        HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(W[k], ws->ev.p + k * n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    }
+    ntt_run(ctx, W[0], log_n, NTT_INVERSE, 3, n4);
+    host::G1AffineH comm[9];
+    for (int k = 0; k < 3; ++k) {
+        const fr_h b2[2] = {bl[2 * k + 1], bl[2 * k]};  // blind poly [b2, b1] (:205-207)
+        poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
+        HIP_CHECK(hipMemcpyAsync(CO[k], W[k], (n + 2) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    }
+    for (int k = 0; k < 3; ++k) comm[k] = commit_dev(ctx, srs, CO[k], n + 2, ws->flag.p);
+    tr.absorb_g1("a_comm", comm[0]);
+    tr.absorb_g1("b_comm", comm[1]);
+    tr.absorb_g1("c_comm", comm[2]);
+    const fr_h beta = tr.squeeze_challenge("beta");
+    const fr_h gamma = tr.squeeze_challenge("gamma");
+
+    // ---- round 2 (prover.rs:247-336) ----
+    {
+        PermArgs p;
+        p.a = ws->ev.p; p.b = ws->ev.p + n; p.c = ws->ev.p + 2 * n;
+        p.s1 = pk->sig_ev.p; p.s2 = pk->sig_ev.p + n; p.s3 = pk->sig_ev.p + 2 * n;
+        p.w_lo = pk->w_lo.p; p.w_hi = pk->w_hi.p;
+        p.num = ws->num.p; p.den = ws->den.p;
+        p.beta = to_dev(beta); p.gamma = to_dev(gamma); p.k1 = to_dev(pk->k1); p.k2 = to_dev(pk->k2);
+        p.n = (uint32_t)n; p.log_l = pk->log_lw;
+        perm_terms(ctx, p);
+        // only i < n-1 enter the product (:271); the last ratio is never read by the exclusive scan
+        perm_ratio(ctx, ws->num.p, ws->den.p, (uint32_t)n - 1, ws->scr.p, ws->flag.p);
+        scan_prefix_product(ctx, ws->den.p, W[3], (uint32_t)n, ws->totals);
+    }
+    ntt_run(ctx, W[3], log_n, NTT_INVERSE, 1, 0);
+    {
+        const fr_h b3[3] = {bl[8], bl[7], bl[6]};  // [b9, b8, b7] (:319)
+        poly_blind(ctx, W[3], (uint32_t)n, b3, 3);
+        HIP_CHECK(hipMemcpyAsync(CO[3], W[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    }
+    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p);
+    check_flag(ctx, ws);
+    tr.absorb_g1("z_comm", comm[3]);
+    const fr_h alpha = tr.squeeze_challenge("alpha");
+
+    // ---- round 3 (prover.rs:339-574) ----
+    bool has_pi = false;
+    if (n_pub && !pk->pi_positions.empty()) {  // prover.rs:840-857
+        std::vector<fr_h> pe(n, Fr::zero());
+        for (size_t i = 0; i < pk->pi_positions.size() && i < n_pub; ++i) pe[pk->pi_positions[i]] = Fr::neg(pi[i]);
+        HIP_CHECK(hipMemcpyAsync(W[4], pe.data(), n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        ntt_run(ctx, W[4], log_n, NTT_INVERSE, 1, 0);
+        has_pi = true;
+    }
+    ntt_run(ctx, W[0], log_n + 2, NTT_COSET, has_pi ? 5 : 4, n4);
+    quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
+    ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
+    poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
+    HIP_CHECK(hipMemcpyAsync(TP[0], ws->t.p, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(TP[1], ws->t.p + n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(TP[2], ws->t.p + 2 * n, std::min(n + 6, n4 - 2 * n) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    poly_poke(ctx, TP[0], (uint32_t)n, bl[9], false);   // t_lo  += b10 X^n   (:540-543)
+    poly_poke(ctx, TP[1], 0, bl[9], true);              // t_mid -= b10
+    poly_poke(ctx, TP[1], (uint32_t)n, bl[10], false);  // t_mid += b11 X^n
+    poly_poke(ctx, TP[2], 0, bl[10], true);             // t_hi  -= b11
+    comm[4] = commit_dev(ctx, srs, TP[0], n + 1, ws->flag.p);
+    comm[5] = commit_dev(ctx, srs, TP[1], n + 1, ws->flag.p);
+    comm[6] = commit_dev(ctx, srs, TP[2], n + 6, ws->flag.p);
+    check_flag(ctx, ws);
+    tr.absorb_g1("t_lo_comm", comm[4]);
+    tr.absorb_g1("t_mid_comm", comm[5]);
+    tr.absorb_g1("t_hi_comm", comm[6]);
+    const fr_h zeta = tr.squeeze_challenge("zeta");
+
+    // ---- round 4 (prover.rs:577-641) ----
+    const fr_h zeta_omega = Fr::mul(zeta, pk->omega);
+    fr_h e6[6];
+    {
+        EvalArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        const fr_t* polys[6] = {CO[0], CO[1], CO[2], pk->coef.p + 5 * n, pk->coef.p + 6 * n, CO[3]};
+        const uint32_t lens[6] = {(uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n, (uint32_t)n, (uint32_t)n + 3};
+        for (int k = 0; k < 6; ++k) {
+            ea.coeffs[k] = polys[k];
+            ea.len[k] = lens[k];
+            ea.x[k] = to_dev(k == 5 ? zeta_omega : zeta);
+        }
+        poly_eval_batch(ctx, ea, 6, ws->evals.p, ws->partial);
+        HIP_CHECK(hipMemcpyAsync(e6, ws->evals.p, 6 * sizeof(fr_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    const fr_h a_bar = e6[0], b_bar = e6[1], c_bar = e6[2], s1_bar = e6[3], s2_bar = e6[4], zw_bar = e6[5];
+    tr.absorb_fr("a_zeta", a_bar);
+    tr.absorb_fr("b_zeta", b_bar);
+    tr.absorb_fr("c_zeta", c_bar);
+    tr.absorb_fr("s_sigma1_zeta", s1_bar);
+    tr.absorb_fr("s_sigma2_zeta", s2_bar);
+    tr.absorb_fr("z_zeta_omega", zw_bar);
+    const fr_h v = tr.squeeze_challenge("v");
+
+    // ---- round 5 (prover.rs:644-837) ----
+    {
+        const fr_h zeta_n = Fr::pow_u64(zeta, n);
+        const fr_h zh_zeta = Fr::sub(zeta_n, Fr::one());                                                  // :697
+        const fr_h l1_den = Fr::mul(Fr::from_u64(n), Fr::sub(zeta, Fr::one()));
+        PLONK_REQUIRE(!Fr::is_zero(l1_den), "prove: zeta = 1");                                           // :700 unwrap
+        const fr_h l1_zeta = Fr::mul(zh_zeta, Fr::inv(l1_den));
+        const fr_h bz = Fr::mul(beta, zeta);
+        fr_h pc1 = Fr::mul(alpha, Fr::add(Fr::add(a_bar, bz), gamma));                                   // :749-752
+        pc1 = Fr::mul(pc1, Fr::add(Fr::add(b_bar, Fr::mul(pk->k1, bz)), gamma));
+        pc1 = Fr::mul(pc1, Fr::add(Fr::add(c_bar, Fr::mul(pk->k2, bz)), gamma));
+        fr_h pc2 = Fr::mul(alpha, Fr::add(Fr::add(a_bar, Fr::mul(beta, s1_bar)), gamma));                // :755-760
+        pc2 = Fr::mul(pc2, Fr::add(Fr::add(b_bar, Fr::mul(beta, s2_bar)), gamma));
+        pc2 = Fr::neg(Fr::mul(Fr::mul(pc2, beta), zw_bar));
+        const fr_h z_coeff = Fr::add(pc1, Fr::mul(Fr::mul(alpha, alpha), l1_zeta));                      // :762,:766
+        const fr_h neg_zh = Fr::neg(zh_zeta);
+        const fr_h v2 = Fr::mul(v, v), v3 = Fr::mul(v2, v), v4 = Fr::mul(v3, v), v5 = Fr::mul(v4, v);
+        LincombArgs la;
+        memset(&la, 0, sizeof(la));
+        uint32_t k = 0;
+        auto term = [&](const fr_t* p, size_t len, const fr_h& s) {
+            la.p[k] = p; la.len[k] = (uint32_t)len; la.s[k] = to_dev(s); ++k;
+        };
+        term(pk->coef.p + 0 * n, n, Fr::mul(a_bar, b_bar));  // q_M  (:742)
+        term(pk->coef.p + 1 * n, n, a_bar);                  // q_L
+        term(pk->coef.p + 2 * n, n, b_bar);                  // q_R
+        term(pk->coef.p + 3 * n, n, c_bar);                  // q_O
+        term(pk->coef.p + 4 * n, n, Fr::one());              // q_C
+        term(CO[3], n + 3, z_coeff);                         // z
+        term(pk->coef.p + 7 * n, n, pc2);                    // S_sigma3 (:763)
+        term(TP[0], n + 1, neg_zh);                          // -Z_H(zeta) (t_lo + zeta^n t_mid + zeta^2n t_hi) (:776-784)
+        term(TP[1], n + 1, Fr::mul(neg_zh, zeta_n));
+        term(TP[2], n + 6, Fr::mul(neg_zh, Fr::mul(zeta_n, zeta_n)));
+        term(CO[0], n + 2, v);                               // :800-807
+        term(CO[1], n + 2, v2);
+        term(CO[2], n + 2, v3);
+        term(pk->coef.p + 5 * n, n, v4);
+        term(pk->coef.p + 6 * n, n, v5);
+        la.count = k;
+        const uint32_t wlen = (uint32_t)n + 6;
+        poly_lincomb(ctx, la, ws->wnum.p, wlen);
+        // subtract the value at zeta (= r(zeta) + v a_bar + ... + v^5 s2_bar) from the constant term
+        EvalArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.coeffs[0] = ws->wnum.p; ea.len[0] = wlen; ea.x[0] = to_dev(zeta);
+        poly_eval_batch(ctx, ea, 1, ws->evals.p + 6, ws->partial);
+        fr_h at_zeta;
+        HIP_CHECK(hipMemcpyAsync(&at_zeta, ws->evals.p + 6, sizeof(fr_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
+        HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
+        poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
+        comm[7] = commit_dev(ctx, srs, ws->wq.p, wlen - 1, ws->flag.p);
+        // W_{zeta omega} = (z - z_bar_omega) / (X - zeta omega)  (:815-816)
+        HIP_CHECK(hipMemcpyAsync(ws->wnum.p, CO[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+        poly_poke(ctx, ws->wnum.p, 0, zw_bar, true);
+        HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
+        poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq.p, ws->totals);
+        comm[8] = commit_dev(ctx, srs, ws->wq.p, n + 2, ws->flag.p);
+        check_flag(ctx, ws);
+    }
+
+    memset(out, 0, sizeof(*out));
+    plonk_g1* g1s[9] = {&out->a_comm, &out->b_comm, &out->c_comm, &out->z_comm, &out->t_lo_comm,
+                        &out->t_mid_comm, &out->t_hi_comm, &out->w_zeta_comm, &out->w_zeta_omega_comm};
+    for (int k = 0; k < 9; ++k) g1_from_host(comm[k], g1s[k]);
+    plonk_fr* frs[6] = {&out->a_eval, &out->b_eval, &out->c_eval, &out->s_sigma1_eval, &out->s_sigma2_eval, &out->z_omega_eval};
+    for (int k = 0; k < 6; ++k) memcpy(frs[k]->l, e6[k].l, 32);
+}
+
+// Re-derives beta, gamma, alpha, zeta, v, u from a proof (the verifier's transcript replay,
+// plonk/verifier.rs:51-92).
+void proof_challenges(const plonk_proof* pr, const plonk_fr* pub, size_t n_pub, plonk_fr out[6]) {
+    auto g = [](const plonk_g1& p) {
+        host::G1AffineH a;
+        memcpy(a.x.l, p.x, 48);
+        memcpy(a.y.l, p.y, 48);
+        a.inf = p.infinity != 0;
+        return a;
+    };
+    auto f = [](const plonk_fr& x) {
+        fr_h h;
+        memcpy(h.l, x.l, 32);
+        return h;
+    };
+    host::Transcript tr("PLONK-v1");
+    for (size_t i = 0; i < n_pub; ++i) tr.absorb_fr("pi_" + std::to_string(i), f(pub[i]));
+    tr.absorb_g1("a_comm", g(pr->a_comm)); tr.absorb_g1("b_comm", g(pr->b_comm)); tr.absorb_g1("c_comm", g(pr->c_comm));
+    fr_h ch[6];
+    ch[0] = tr.squeeze_challenge("beta");
+    ch[1] = tr.squeeze_challenge("gamma");
+    tr.absorb_g1("z_comm", g(pr->z_comm));
+    ch[2] = tr.squeeze_challenge("alpha");
+    tr.absorb_g1("t_lo_comm", g(pr->t_lo_comm)); tr.absorb_g1("t_mid_comm", g(pr->t_mid_comm));
+    tr.absorb_g1("t_hi_comm", g(pr->t_hi_comm));
+    ch[3] = tr.squeeze_challenge("zeta");
+    tr.absorb_fr("a_zeta", f(pr->a_eval)); tr.absorb_fr("b_zeta", f(pr->b_eval)); tr.absorb_fr("c_zeta", f(pr->c_eval));
+    tr.absorb_fr("s_sigma1_zeta", f(pr->s_sigma1_eval)); tr.absorb_fr("s_sigma2_zeta", f(pr->s_sigma2_eval));
+    tr.absorb_fr("z_zeta_omega", f(pr->z_omega_eval));
+    ch[4] = tr.squeeze_challenge("v");
+    tr.absorb_g1("w_zeta_comm", g(pr->w_zeta_comm)); tr.absorb_g1("w_zeta_omega_comm", g(pr->w_zeta_omega_comm));
+    ch[5] = tr.squeeze_challenge("u");
+    for (int k = 0; k < 6; ++k) memcpy(out[k].l, ch[k].l, 32);
+}
+
+}  // namespace plonk

@@ -1,0 +1,34 @@
+// Host-side declarations of the proving key and prover (prover.hip).
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+#include "msm.hpp"
+
+namespace plonk {
+
+// ProvingKey of backend_new/src/plonk/types.rs:12, resident on one device.
+struct Pk {
+    int device = 0;
+    uint32_t log_n = 0;
+    size_t n = 0;
+    host::fr_h k1, k2, omega;
+    std::vector<uint32_t> pi_positions;
+    DevBuf<fr_t> coef;    // [9][n]  coefficients: q_m q_l q_r q_o q_c s1 s2 s3 l1
+    DevBuf<fr_t> ext;     // [9][4n] evaluations on the coset 7*H_4n
+    DevBuf<fr_t> sig_ev;  // [3][n]  S_sigma evaluations on H
+    DevBuf<fr_t> w_lo, w_hi, x_lo, x_hi;
+    uint32_t log_lw = 0, log_lx = 0;
+    host::fr_h zh_inv[4];
+};
+
+Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const host::fr_h& k1,
+              const host::fr_h& k2, const uint32_t* pi_pos, size_t n_pi_pos);
+void quotient_3wire(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr_t* pi, const host::fr_h& alpha,
+                    const host::fr_h& beta, const host::fr_h& gamma, fr_t* t_out);
+host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len);
+void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
+                 const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out);
+void proof_challenges(const plonk_proof* pr, const plonk_fr* pub, size_t n_pub, plonk_fr out[6]);
+
+}  // namespace plonk
