@@ -96,6 +96,9 @@ int32_t plonk_srs_upload(plonk_ctx* ctx, const plonk_g1* g1_powers, size_t n, pl
 /* [tau^i]_1 for i in [0, n) generated on the device from a known tau (Montgomery Fr):
  * the group elements of Srs::from_tau (kzg.rs:71-94).  For synthetic benchmarks and tests. */
 int32_t plonk_srs_from_tau(plonk_ctx* ctx, const plonk_fr* tau, size_t n, plonk_srs** out);
+/* The slice [first, first + count) of the same sequence: one rank's share when the commitment
+ * MSMs are sharded by point range over the GPUs of a node. */
+int32_t plonk_srs_from_tau_range(plonk_ctx* ctx, const plonk_fr* tau, size_t first, size_t count, plonk_srs** out);
 size_t plonk_srs_len(const plonk_srs* srs);
 int32_t plonk_srs_download(plonk_ctx* ctx, const plonk_srs* srs, size_t first, size_t count, plonk_g1* out);
 void plonk_srs_free(plonk_srs* srs);
@@ -147,6 +150,28 @@ int32_t plonk_prove_3wire(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* s
                           const plonk_fr* b_evals, const plonk_fr* c_evals, const plonk_fr* public_inputs,
                           size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out);
 
+/* Same with the three wire-evaluation vectors already resident on the device. */
+int32_t plonk_prove_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, const plonk_fr* a_evals_dev,
+                              const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev, const plonk_fr* public_inputs,
+                              size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out);
+
+/* ---- multi-GPU: the nine commitment MSMs sharded by point range, one process per GPU.
+ * `srs_slice` holds g1_powers[shard_lo, shard_lo + len) (plonk_srs_from_tau_range or an upload of
+ * that slice); every rank passes the same witness and key.  After each local partial MSM the
+ * library calls `allgather(user, send, bytes, recv)`, which must fill recv with the `bytes`-sized
+ * records of all `world` ranks in rank order (RCCL/NCCL all-gather in practice) and return 0.
+ * All ranks obtain the same proof.  No counterpart in the single-process reference. */
+typedef int32_t (*plonk_allgather_fn)(void* user, const void* send, size_t bytes, void* recv);
+int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
+                                  uint32_t world, plonk_allgather_fn allgather, void* user,
+                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
+                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
+                                  plonk_proof* out);
+/* Sum of n affine points on the host (combining per-rank partial commitments). */
+int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out);
+/* Window width c (bits) the MSM uses for n points: W = ceil(256/c) windows of 2^(c-1) buckets. */
+uint32_t plonk_msm_window_bits(size_t n);
+
 /* ---- encodings (host only, no device work) ---- */
 /* G1Affine::to_compressed_bytes (curve.rs:84-88). */
 int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]);
@@ -166,6 +191,11 @@ int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_
  * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
  * priced against).  which: 0 = Fr, 1 = Fq. */
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second);
+/* HIP-event stopwatch on the ctx stream (the stream every kernel of this ctx runs on): start
+ * records an event, stop records a second one, waits for it and returns the elapsed device
+ * time between the two in milliseconds. */
+int32_t plonk_timer_start(plonk_ctx* ctx);
+int32_t plonk_timer_stop(plonk_ctx* ctx, double* elapsed_ms);
 
 #ifdef __cplusplus
 }

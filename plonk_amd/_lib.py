@@ -48,6 +48,7 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 _u32 = C.c_uint32
 _i32 = C.c_int32
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # name -> (restype, argtypes); kept in the order of include/plonk_hip.h
 SIGNATURES = {
@@ -64,6 +65,7 @@ SIGNATURES = {
     "plonk_ntt": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _sz]),
     "plonk_srs_upload": (_i32, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "plonk_srs_from_tau": (_i32, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "plonk_srs_from_tau_range": (_i32, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "plonk_srs_len": (_sz, [_vp]),
     "plonk_srs_download": (_i32, [_vp, _vp, _sz, _sz, _vp]),
     "plonk_srs_free": (None, [_vp]),
@@ -76,12 +78,18 @@ SIGNATURES = {
     "plonk_pk_poly": (_i32, [_vp, _vp, _u32, _vp, C.POINTER(_sz)]),
     "plonk_quotient_3wire_dev": (_i32, [_vp] * 11),
     "plonk_prove_3wire": (_i32, [_vp] * 7 + [_sz, _vp, _vp]),
+    "plonk_prove_3wire_dev": (_i32, [_vp] * 7 + [_sz, _vp, _vp]),
+    "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "plonk_g1_sum": (_i32, [_vp, _sz, _vp]),
+    "plonk_msm_window_bits": (_u32, [_sz]),
     "plonk_g1_compress": (_i32, [_vp, _vp]),
     "plonk_fr_to_bytes": (_i32, [_vp, _vp]),
     "plonk_fr_from_bytes": (_i32, [_vp, _vp]),
     "plonk_proof_serialize": (_i32, [_vp, _vp]),
     "plonk_proof_challenges": (_i32, [_vp, _vp, _sz, _vp]),
     "plonk_bench_field_mul": (_i32, [_vp, _u32, C.POINTER(C.c_double)]),
+    "plonk_timer_start": (_i32, [_vp]),
+    "plonk_timer_stop": (_i32, [_vp, C.POINTER(C.c_double)]),
 }
 
 

@@ -147,6 +147,14 @@ class Context:
         sh = C.byref(_fr_struct(shift)) if shift is not None else None
         self.check(lib.plonk_ntt_dev(self.h, dev, log_n, flags, sh, batch, stride or (1 << log_n)))
 
+    def timer_start(self):
+        self.check(lib.plonk_timer_start(self.h))
+
+    def timer_stop(self):
+        v = C.c_double()
+        self.check(lib.plonk_timer_stop(self.h, C.byref(v)))
+        return v.value
+
     def bench_field_mul(self, which):
         v = C.c_double()
         self.check(lib.plonk_bench_field_mul(self.h, which, C.byref(v)))
@@ -272,6 +280,21 @@ class Srs:
         ctx.check(lib.plonk_srs_from_tau(ctx.h, C.byref(t), max_degree + 1, C.byref(h)))
         return cls(h, ctx)
 
+    @classmethod
+    def from_tau_range(cls, tau, first, end, ctx=None):
+        """[tau^i]_1 for i in [first, end): one rank's slice of the point range."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        t = _fr_struct(tau)
+        ctx.check(lib.plonk_srs_from_tau_range(ctx.h, C.byref(t), first, end - first, C.byref(h)))
+        return cls(h, ctx)
+
+    def commit_dev(self, coeffs_dev, length):
+        """Commitment::commit over a coefficient vector already on the device."""
+        out = _lib.G1()
+        self.ctx.check(lib.plonk_commit_dev(self.ctx.h, self.h, coeffs_dev, length, C.byref(out)))
+        return _g1_value(out)
+
     def __len__(self):
         return lib.plonk_srs_len(self.h)
 
@@ -309,6 +332,10 @@ class Commitment:
         out = _lib.G1()
         srs.ctx.check(lib.plonk_commit(srs.ctx.h, srs.h, _ptr(a), a.shape[0], C.byref(out)))
         return Commitment(_g1_value(out))
+
+
+def msm_window_bits(n):
+    return lib.plonk_msm_window_bits(n)
 
 
 def msm(points, scalars, ctx=None):
@@ -404,9 +431,24 @@ class Prover:
     eleven blinding scalars from thread_rng (prover.rs:189-194, 310-312, 537-538); here the caller
     passes them (`blinding`), or they come from os.urandom."""
 
-    def __init__(self, wires, pk, srs):
+    def __init__(self, wires, pk, srs, resident=False, comm=None, shard=None):
+        """comm/shard: multi-GPU proving (plonk_amd.sharded): `srs` is then this rank's slice
+        [shard[0], shard[1]) of g1_powers and `comm` a sharded.Communicator."""
         self.pk, self.srs = pk, srs
         self.wires = [_as_limbs(w, pk.n) for w in wires]
+        self.dev = None
+        self.comm, self.shard = comm, shard
+        if resident or comm is not None:  # keep the witness in HBM: prove() then starts from device buffers
+            ctx = pk.ctx
+            self.dev = [ctx.alloc(w.nbytes) for w in self.wires]
+            for d, w in zip(self.dev, self.wires):
+                ctx.upload(d, w)
+
+    def close(self):
+        if self.dev:
+            for d in self.dev:
+                self.pk.ctx.free(d)
+            self.dev = None
 
     def prove(self, public_inputs=(), blinding=None):
         import os
@@ -418,6 +460,14 @@ class Prover:
         pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])
         raw = _lib.Proof()
         ctx = self.pk.ctx
-        ctx.check(lib.plonk_prove_3wire(ctx.h, self.pk.h, self.srs.h, _ptr(self.wires[0]), _ptr(self.wires[1]),
-                                        _ptr(self.wires[2]), pis, len(public_inputs), bl, C.byref(raw)))
+        if self.comm is not None:
+            ctx.check(lib.plonk_prove_3wire_sharded(ctx.h, self.pk.h, self.srs.h, self.shard[0], self.comm.world,
+                                                    self.comm.callback, None, self.dev[0], self.dev[1], self.dev[2],
+                                                    pis, len(public_inputs), bl, C.byref(raw)))
+        elif self.dev:
+            ctx.check(lib.plonk_prove_3wire_dev(ctx.h, self.pk.h, self.srs.h, self.dev[0], self.dev[1], self.dev[2],
+                                                pis, len(public_inputs), bl, C.byref(raw)))
+        else:
+            ctx.check(lib.plonk_prove_3wire(ctx.h, self.pk.h, self.srs.h, _ptr(self.wires[0]), _ptr(self.wires[1]),
+                                            _ptr(self.wires[2]), pis, len(public_inputs), bl, C.byref(raw)))
         return Proof(raw)

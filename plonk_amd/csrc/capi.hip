@@ -176,7 +176,15 @@ int32_t plonk_srs_from_tau(plonk_ctx* ctx, const plonk_fr* tau, size_t n, plonk_
     if (!ctx || !out) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     *out = nullptr;
-    *out = reinterpret_cast<plonk_srs*>(srs_from_tau(C_, fr_in(tau, "srs tau"), n));
+    *out = reinterpret_cast<plonk_srs*>(srs_from_tau(C_, fr_in(tau, "srs tau"), 0, n));
+    API_END()
+}
+
+int32_t plonk_srs_from_tau_range(plonk_ctx* ctx, const plonk_fr* tau, size_t first, size_t count, plonk_srs** out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    *out = reinterpret_cast<plonk_srs*>(srs_from_tau(C_, fr_in(tau, "srs tau"), first, count));
     API_END()
 }
 
@@ -305,7 +313,73 @@ int32_t plonk_prove_3wire(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* s
     const Pk* k = reinterpret_cast<const Pk*>(pk);
     const Srs* s = reinterpret_cast<const Srs*>(srs);
     PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
-    prove_3wire(C_, k, s, a_evals, b_evals, c_evals, public_inputs, n_public_inputs, blinding, out);
+    prove_3wire(C_, k, s, a_evals, b_evals, c_evals, false, public_inputs, n_public_inputs, blinding, out);
+    API_END()
+}
+
+int32_t plonk_prove_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, const plonk_fr* a_evals_dev,
+                              const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev, const plonk_fr* public_inputs,
+                              size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out) {
+    if (!ctx || !pk || !srs || !a_evals_dev || !b_evals_dev || !c_evals_dev || !blinding || !out) return PLONK_E_INVALID;
+    if (n_public_inputs && !public_inputs) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
+    prove_3wire(C_, k, s, a_evals_dev, b_evals_dev, c_evals_dev, true, public_inputs, n_public_inputs, blinding, out);
+    API_END()
+}
+
+int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
+                                  uint32_t world, plonk_allgather_fn allgather, void* user,
+                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
+                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
+                                  plonk_proof* out) {
+    if (!ctx || !pk || !srs_slice || !a_evals_dev || !b_evals_dev || !c_evals_dev || !blinding || !out) return PLONK_E_INVALID;
+    if (n_public_inputs && !public_inputs) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    PLONK_REQUIRE(world >= 1, "prove: world must be >= 1");
+    PLONK_REQUIRE(world == 1 || allgather != nullptr, "prove: sharded proving needs an all-gather callback");
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(srs_slice);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
+    ShardInfo sh;
+    sh.lo = shard_lo;
+    sh.world = world;
+    sh.allgather = allgather;
+    sh.user = user;
+    prove_3wire(C_, k, s, a_evals_dev, b_evals_dev, c_evals_dev, true, public_inputs, n_public_inputs, blinding, out, &sh);
+    API_END()
+}
+
+int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out) {
+    if (!out || (n && !points)) return PLONK_E_INVALID;
+    g1_from_host(g1_sum_affine(points, n), out);
+    return PLONK_OK;
+}
+
+uint32_t plonk_msm_window_bits(size_t n) { return msm_window_bits(n); }
+
+int32_t plonk_timer_start(plonk_ctx* ctx) {
+    if (!ctx) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    if (!C_->ev0) {
+        HIP_CHECK(hipEventCreate(&C_->ev0));
+        HIP_CHECK(hipEventCreate(&C_->ev1));
+    }
+    HIP_CHECK(hipEventRecord(C_->ev0, C_->stream));
+    API_END()
+}
+
+int32_t plonk_timer_stop(plonk_ctx* ctx, double* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    PLONK_REQUIRE(C_->ev0 != nullptr, "timer: stop without start");
+    HIP_CHECK(hipEventRecord(C_->ev1, C_->stream));
+    HIP_CHECK(hipEventSynchronize(C_->ev1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, C_->ev0, C_->ev1));
+    *elapsed_ms = ms;
     API_END()
 }
 

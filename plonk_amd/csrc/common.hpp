@@ -63,6 +63,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;               // plonk_timer_start / _stop
     std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9
     DevBuf<fr_t> ntt_tmp;                                  // intermediate image of a multi-pass NTT
     std::shared_ptr<void> msm_ws;                          // MsmWorkspace (msm.hip)

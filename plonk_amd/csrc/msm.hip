@@ -365,13 +365,14 @@ static const std::vector<g1_affine_t>& fixed_base_table() {
     return table;
 }
 
-__global__ __launch_bounds__(256) void srs_powers_kernel(fr_t tau, uint32_t n, const g1_affine_t* __restrict__ table,
+__global__ __launch_bounds__(256) void srs_powers_kernel(fr_t tau, uint64_t first, uint32_t n,
+                                                          const g1_affine_t* __restrict__ table,
                                                           g1_xyzz_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // tau^i by square-and-multiply
+    // tau^(first + i) by square-and-multiply
     fr_t r = f_one<FrP>(), b = tau;
-    for (uint32_t e = i; e; e >>= 1) {
+    for (uint64_t e = first + i; e; e >>= 1) {
         if (e & 1u) r = fr_mul(r, b);
         b = fr_mul(b, b);
     }
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_kernel(const g1_xyzz_t* __
     }
 }
 
-Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t n) {
+Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n) {
     PLONK_REQUIRE(n < ((size_t)1 << 31), "srs: too many points");
     std::unique_ptr<Srs> s(new Srs());
     s->device = ctx->device;
@@ -457,8 +458,8 @@ Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t n) {
     DevBuf<g1_xyzz_t> tmp(n);
     DevBuf<fq_t> prefix(n);
     const uint32_t nblk = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(srs_powers_kernel, dim3(nblk), dim3(256), 0, ctx->stream, to_dev(tau), (uint32_t)n, table_dev.p,
-                       tmp.p);
+    hipLaunchKernelGGL(srs_powers_kernel, dim3(nblk), dim3(256), 0, ctx->stream, to_dev(tau), (uint64_t)first, (uint32_t)n,
+                       table_dev.p, tmp.p);
     const uint32_t ch = 16;
     const uint32_t lanes = (uint32_t)((n + ch - 1) / ch);
     hipLaunchKernelGGL(xyzz_to_affine_kernel, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, tmp.p, (uint32_t)n, ch,

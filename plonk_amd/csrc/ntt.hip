@@ -189,6 +189,8 @@ Ctx::~Ctx() {
     msm_ws.reset();
     prover_ws.reset();
     ntt_tmp.release();
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -191,12 +191,36 @@ static ProverWorkspace* prover_workspace(Ctx* ctx) {
     return static_cast<ProverWorkspace*>(ctx->prover_ws.get());
 }
 
-static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev) {
+host::G1AffineH g1_sum_affine(const plonk_g1* pts, size_t n) {
+    host::G1XyzzH acc = host::g1_identity();
+    for (size_t i = 0; i < n; ++i) {
+        host::G1AffineH a;
+        memcpy(a.x.l, pts[i].x, 48);
+        memcpy(a.y.l, pts[i].y, 48);
+        a.inf = pts[i].infinity != 0;
+        acc = host::g1_add(acc, host::g1_from_affine(a));
+    }
+    return host::g1_to_affine(acc);
+}
+
+static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
+                                  const ShardInfo* shard = nullptr) {
     // kzg.rs:231-245.  Coefficients past the SRS must be zero (the reference strips trailing zeros
     // before its length check and panics otherwise).
-    size_t m = std::min(len, srs->n);
-    if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
-    return msm_run(ctx, srs->points.p, coeffs, m);
+    if (!shard || shard->world <= 1) {
+        size_t m = std::min(len, srs->n);
+        if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
+        return msm_run(ctx, srs->points.p, coeffs, m);
+    }
+    // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
+    const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
+    host::G1AffineH part = msm_run(ctx, srs->points.p, coeffs + lo, hi - lo);
+    plonk_g1 mine;
+    g1_from_host(part, &mine);
+    std::vector<plonk_g1> all(shard->world);
+    const int rc = shard->allgather(shard->user, &mine, sizeof(plonk_g1), all.data());
+    if (rc != 0) throw Error(PLONK_E_INTERNAL, "commit: all-gather of the MSM partial sums failed");
+    return g1_sum_affine(all.data(), all.size());
 }
 
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
@@ -219,10 +243,10 @@ static void check_flag(Ctx* ctx, ProverWorkspace* ws) {
 }
 
 void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
-                 const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out) {
+                 bool evals_on_device, const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out,
+                 const ShardInfo* shard) {
     const size_t n = pk->n, n4 = 4 * n, ns = n + 8;
     const uint32_t log_n = pk->log_n;
-    PLONK_REQUIRE(srs->n >= 1, "prove: empty SRS");
     ProverWorkspace* ws = prover_workspace(ctx);
     ws->w4.ensure(5 * n4); ws->t.ensure(n4); ws->ev.ensure(3 * n); ws->co.ensure(4 * ns);
     ws->num.ensure(n); ws->den.ensure(n); ws->scr.ensure(n); ws->tp.ensure(3 * ns);
@@ -256,7 +280,8 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     // ---- round 1 (prover.rs:181-244) ----
     const plonk_fr* evs[3] = {a_ev, b_ev, c_ev};
     for (int k = 0; k < 3; ++k) {
-        HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t),
+                                 evals_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(W[k], ws->ev.p + k * n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
     }
     ntt_run(ctx, W[0], log_n, NTT_INVERSE, 3, n4);
@@ -266,7 +291,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
         HIP_CHECK(hipMemcpyAsync(CO[k], W[k], (n + 2) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
     }
-    for (int k = 0; k < 3; ++k) comm[k] = commit_dev(ctx, srs, CO[k], n + 2, ws->flag.p);
+    for (int k = 0; k < 3; ++k) comm[k] = commit_dev(ctx, srs, CO[k], n + 2, ws->flag.p, shard);
     tr.absorb_g1("a_comm", comm[0]);
     tr.absorb_g1("b_comm", comm[1]);
     tr.absorb_g1("c_comm", comm[2]);
@@ -293,7 +318,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_blind(ctx, W[3], (uint32_t)n, b3, 3);
         HIP_CHECK(hipMemcpyAsync(CO[3], W[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
     }
-    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p);
+    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard);
     check_flag(ctx, ws);
     tr.absorb_g1("z_comm", comm[3]);
     const fr_h alpha = tr.squeeze_challenge("alpha");
@@ -319,9 +344,9 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     poly_poke(ctx, TP[1], 0, bl[9], true);              // t_mid -= b10
     poly_poke(ctx, TP[1], (uint32_t)n, bl[10], false);  // t_mid += b11 X^n
     poly_poke(ctx, TP[2], 0, bl[10], true);             // t_hi  -= b11
-    comm[4] = commit_dev(ctx, srs, TP[0], n + 1, ws->flag.p);
-    comm[5] = commit_dev(ctx, srs, TP[1], n + 1, ws->flag.p);
-    comm[6] = commit_dev(ctx, srs, TP[2], n + 6, ws->flag.p);
+    comm[4] = commit_dev(ctx, srs, TP[0], n + 1, ws->flag.p, shard);
+    comm[5] = commit_dev(ctx, srs, TP[1], n + 1, ws->flag.p, shard);
+    comm[6] = commit_dev(ctx, srs, TP[2], n + 6, ws->flag.p, shard);
     check_flag(ctx, ws);
     tr.absorb_g1("t_lo_comm", comm[4]);
     tr.absorb_g1("t_mid_comm", comm[5]);
@@ -406,13 +431,13 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
-        comm[7] = commit_dev(ctx, srs, ws->wq.p, wlen - 1, ws->flag.p);
+        comm[7] = commit_dev(ctx, srs, ws->wq.p, wlen - 1, ws->flag.p, shard);
         // W_{zeta omega} = (z - z_bar_omega) / (X - zeta omega)  (:815-816)
         HIP_CHECK(hipMemcpyAsync(ws->wnum.p, CO[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
         poly_poke(ctx, ws->wnum.p, 0, zw_bar, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq.p, ws->totals);
-        comm[8] = commit_dev(ctx, srs, ws->wq.p, n + 2, ws->flag.p);
+        comm[8] = commit_dev(ctx, srs, ws->wq.p, n + 2, ws->flag.p, shard);
         check_flag(ctx, ws);
     }
 

@@ -22,13 +22,24 @@ struct Pk {
     host::fr_h zh_inv[4];
 };
 
+// Point-range sharding of the commitment MSMs over the ranks of one node: this rank's SRS handle
+// holds g1_powers[lo, lo + srs->n); `allgather` exchanges one plonk_g1 per rank (rank order).
+struct ShardInfo {
+    size_t lo = 0;
+    uint32_t world = 1;
+    plonk_allgather_fn allgather = nullptr;
+    void* user = nullptr;
+};
+
 Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const host::fr_h& k1,
               const host::fr_h& k2, const uint32_t* pi_pos, size_t n_pi_pos);
 void quotient_3wire(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr_t* pi, const host::fr_h& alpha,
                     const host::fr_h& beta, const host::fr_h& gamma, fr_t* t_out);
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len);
 void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
-                 const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out);
+                 bool evals_on_device, const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out,
+                 const ShardInfo* shard = nullptr);
+host::G1AffineH g1_sum_affine(const plonk_g1* pts, size_t n);
 void proof_challenges(const plonk_proof* pr, const plonk_fr* pub, size_t n_pub, plonk_fr out[6]);
 
 }  // namespace plonk

@@ -1,0 +1,76 @@
+"""world_size-2 rehearsal of the sharded-commit exchange on CPU (gloo): point-range split,
+all-gather of the per-rank partial commitments through the same callback object the C library
+calls, and the host-side combine (plonk_g1_sum).  The per-rank partial MSMs come from the oracle
+here (no GPU); on MI355X they come from the HIP MSM through plonk_prove_3wire_sharded."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from plonk_amd import sharded, _lib
+from plonk_amd.api import _g1_struct, _g1_value
+from oracle import curve, protocol as P
+import random
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+comm = sharded.Communicator(dist, rank, world)
+n_points = 37
+srs = P.Srs(0xD15EA5E, n_points - 1)
+rng = random.Random(5)
+coeffs = [rng.randrange(1 << 250) for _ in range(n_points - 4)]   # polynomial shorter than the SRS
+lo, hi = sharded.point_range(n_points, rank, world)
+lo_c, hi_c = min(lo, len(coeffs)), min(hi, len(coeffs))
+part = curve.to_affine(curve.msm(srs.g1_powers[lo_c:hi_c], coeffs[lo_c:hi_c]))
+# go through the C-callable callback exactly as the library does
+mine = _g1_struct(part)
+recv = (_lib.G1 * world)()
+rc = comm.callback(None, C.cast(C.byref(mine), C.c_void_p), C.sizeof(_lib.G1), C.cast(recv, C.c_void_p))
+assert rc == 0 and comm.calls == 1
+total = sharded.combine_partials([_g1_value(g) for g in recv])
+assert total == P.commit(coeffs, srs), "combined partial commitments differ from the full commitment"
+# every rank must hold the same bytes (same transcript on all ranks)
+blobs = comm.allgather_bytes(curve.compress(total))
+assert blobs[:48] == blobs[48:96]
+# an empty slice contributes the identity
+assert sharded.combine_partials([None, part, None]) == part
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_point_range_partition():
+    from plonk_amd import sharded
+    for n in (0, 1, 7, 8, 1048587):
+        for world in (1, 2, 3, 8):
+            rs = [sharded.point_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_commit_exchange_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out

@@ -1,0 +1,346 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle: bit-exact everywhere.
+Small sizes against the Python oracle and the committed golden fixtures, larger ones against the
+C restatement, full BASELINE sizes through size-independent properties."""
+import ctypes as C
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import cref, curve, fft as offt, protocol as P
+from oracle.field import R_MOD, root_of_unity, fr_to_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(seed, n):
+    rng = random.Random(seed)
+    return [rng.randrange(R_MOD) for _ in range(n)]
+
+
+def _modes(v, n):
+    w = root_of_unity(n)
+    return [offt.fft(v, w, n), (offt.ifft(v, w) + [0] * n)[:n], offt.coset_fft(v, w, 7, n), offt.coset_ifft(v, w, 7)]
+
+
+# ------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 7, 10, 11, 12, 13, 15])
+def test_ntt_matches_oracle(ctx, log_n):
+    import plonk_amd as pa
+    n = 1 << log_n
+    v = _rand(log_n, n)
+    exp = _modes(v, n)
+    for flags in range(4):
+        got = pa.fr_from_array(ctx.ntt(pa.fr_to_array(v), flags))
+        assert got == exp[flags], (log_n, flags)
+
+
+def test_ntt_reference_interface_and_kats(ctx):
+    """fft.rs:278-318 through the mirrored API."""
+    import plonk_amd as pa
+    w8, w4 = pa.api.root_of_unity(8), pa.api.root_of_unity(4)
+    assert pa.ifft(pa.fft([1, 2, 3, 4], w8, 8), w8) == [1, 2, 3, 4]
+    ev = pa.fft([1, 2, 3], w4, 4)
+    assert ev == [P.poly_eval([1, 2, 3], pow(w4, i, R_MOD)) for i in range(4)]
+    d = pa.Domain(16)
+    v = _rand(1, 16)
+    assert d.coset_ifft(d.coset_fft(v, 7), 7) == v
+    assert d.coset_fft(v, 5) == offt.coset_fft(v, d.omega, 5, 16)  # arbitrary shift
+    assert d.ifft(d.fft(v[:10])) == v[:10]
+    assert pa.ifft([0] * 8, w8) == []  # normalised: the zero polynomial
+    with pytest.raises(pa.PlonkError):
+        pa.fft([1, 2, 3], w4, 3)  # fft.rs:24 "FFT size must be a power of 2"
+    with pytest.raises(pa.PlonkError):
+        pa.fft([1] * 5, w4, 4)
+
+
+def test_ntt_golden(ctx):
+    import plonk_amd as pa
+    for e in golden("ntt.json"):
+        n = e["n"]
+        v = _rand(e["seed"], n)
+        for flags, k in enumerate(("fft", "ifft", "coset_fft", "coset_ifft")):
+            got = pa.fr_from_array(ctx.ntt(pa.fr_to_array(v), flags))
+            assert hashlib.sha256(b"".join(fr_to_bytes(x) for x in got)).hexdigest() == e["sha256"][k]
+
+
+def test_ntt_batched_and_strided(ctx):
+    import plonk_amd as pa
+    n, batch = 1 << 12, 3
+    vs = [_rand(50 + b, n) for b in range(batch)]
+    arr = np.concatenate([pa.fr_to_array(v) for v in vs])
+    ctx.ntt(arr, 2, batch=batch)
+    w = root_of_unity(n)
+    for b in range(batch):
+        assert pa.fr_from_array(arr[b * n:(b + 1) * n]) == offt.coset_fft(vs[b], w, 7, n)
+
+
+@pytest.mark.parametrize("log_n,flags", [(16, 0), (17, 3), (18, 2), (20, 0), (20, 3)])
+def test_ntt_matches_c_restatement(ctx, log_n, flags):
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n * 7 + flags)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)  # Montgomery images below 2^254 < r
+    exp = cref.ntt(a.copy(), flags)
+    got = ctx.ntt(a.copy(), flags)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_ntt_full_size_properties(ctx, log_n):
+    """BASELINE sizes (4n for n = 2^20, and 2^24): round trips, linearity, known transforms."""
+    import plonk_amd as pa
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    f = ctx.ntt(a.copy(), 0)
+    assert np.array_equal(ctx.ntt(f.copy(), 1), a)                       # ifft(fft(x)) == x
+    c = ctx.ntt(a.copy(), 2)
+    assert np.array_equal(ctx.ntt(c.copy(), 3), a)                       # coset round trip
+    # spot values: fft(x)[k] == sum x_i w^(ik) for a sparse x
+    sparse = np.zeros((n, 4), dtype=np.uint64)
+    idx = [0, 1, 5, n // 2 + 3, n - 1]
+    vals = _rand(9, len(idx))
+    sparse[idx] = pa.fr_to_array(vals)
+    fs = ctx.ntt(sparse, 0)
+    w = root_of_unity(n)
+    for k in (0, 1, 2, 12345, n // 2, n - 1):
+        exp = sum(v * pow(w, i * k % n, R_MOD) for i, v in zip(idx, vals)) % R_MOD
+        assert pa.fr_from_array(fs[k:k + 1]) == [exp]
+    # delta at position 1 -> powers of w (and 7w for the coset form)
+    delta = np.zeros((n, 4), dtype=np.uint64)
+    delta[1] = pa.fr_to_array([1])[0]
+    fd = ctx.ntt(delta, 2)
+    for k in (0, 3, n - 1):
+        assert pa.fr_from_array(fd[k:k + 1]) == [7 * pow(w, k, R_MOD) % R_MOD]
+
+
+# ------------------------------------------------------------------ MSM / SRS / commit
+def test_msm_kats_and_edges(ctx):
+    """curve.rs:535-544 and the degenerate inputs."""
+    import plonk_amd as pa
+    G = curve.G1_GEN
+    assert pa.msm([G, G, G], [1, 2, 3]) == curve.to_affine(curve.scalar_mul(G, 6))
+    assert pa.msm([], []) is None
+    assert pa.msm([G, G], [0, 0]) is None
+    assert pa.msm([None, G], [5, 7]) == curve.to_affine(curve.scalar_mul(G, 7))
+    assert pa.msm([G, curve.affine_neg(G)], [9, 9]) is None
+    assert pa.msm([G, G], [4, 4]) == curve.to_affine(curve.scalar_mul(G, 8))   # equal points: doubling path
+    assert pa.msm([G], [R_MOD - 1]) == curve.affine_neg(G)
+
+
+def test_msm_golden_and_oracle(ctx):
+    import plonk_amd as pa
+    for e in golden("msm.json"):
+        sc = _rand(e["scalar_seed"], e["n"])
+        tau = int(e["tau"], 16)
+        if "points" in e:
+            pts = [curve.decompress(bytes.fromhex(p)) for p in e["points"]]
+            assert curve.compress(pa.msm(pts, sc)).hex() == e["commit"]
+        srs = pa.Srs.from_tau(tau, e["n"] - 1)
+        assert curve.compress(pa.Commitment.commit(sc, srs).point).hex() == e["commit"]
+    srs_o = P.Srs(31337, 99)
+    sc = _rand(4, 100)
+    assert pa.msm(srs_o.g1_powers, sc) == curve.to_affine(curve.msm(srs_o.g1_powers, sc))
+
+
+@pytest.mark.parametrize("n", [1, 2, 18, 22, 100, 700, 3000])
+def test_srs_and_commit_trapdoor(ctx, n):
+    """commit(f) == f(tau) * G for an SRS built from a known tau (kzg.rs:71-94, 231-245)."""
+    import plonk_amd as pa
+    tau = _rand(21, 1)[0]
+    srs = pa.Srs.from_tau(tau, n - 1)
+    assert len(srs) == n and srs.max_degree == n - 1
+    if n <= 100:
+        assert srs.g1_powers() == P.Srs(tau, n - 1).g1_powers
+    G = curve.G1_GEN
+    for sc in (_rand(n, n), [random.Random(n).choice([0, 1, R_MOD - 1, 2, 255]) for _ in range(n)]):
+        assert pa.Commitment.commit(sc, srs).point == curve.to_affine(curve.scalar_mul(G, P.poly_eval(sc, tau)))
+    assert pa.Commitment.commit([], srs).point is None
+    assert pa.Commitment.commit([0, 0], srs).point is None if n >= 2 else True
+    with pytest.raises(pa.PlonkError):  # kzg.rs:232-238 panics
+        pa.Commitment.commit([1] * (n + 1), srs)
+    assert pa.Commitment.commit([5] + [0] * n, srs).point == curve.to_affine(curve.scalar_mul(G, 5))  # normalised
+
+
+def test_srs_upload_roundtrip(ctx):
+    import plonk_amd as pa
+    o = P.Srs(777, 20)
+    pts = list(o.g1_powers)
+    pts[3] = None
+    srs = pa.Srs.from_points(pts)
+    assert srs.g1_powers() == pts
+    sc = _rand(6, 21)
+    assert pa.Commitment.commit(sc, srs).point == curve.to_affine(curve.msm(pts, sc))
+    with pytest.raises(pa.PlonkError):
+        pa.Srs.from_points([(1, 2)])  # not on the curve
+
+
+@pytest.mark.parametrize("log_n", [14, 16])
+def test_msm_matches_c_restatement(ctx, log_n):
+    import plonk_amd as pa
+    n = 1 << log_n
+    srs = pa.Srs.from_tau(123456789, n - 1)
+    pts = np.zeros((n, 12), dtype=np.uint64)
+    raw = (pa._lib.G1 * n)()
+    ctx.check(pa._lib.lib.plonk_srs_download(ctx.h, srs.h, 0, n, raw))
+    buf = np.frombuffer(raw, dtype=np.uint64).reshape(n, 13)
+    pts[:] = buf[:, :12]
+    rng = np.random.default_rng(log_n)
+    sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    out = pa._lib.G1()
+    ctx.check(pa._lib.lib.plonk_commit(ctx.h, srs.h, sc.ctypes.data_as(C.c_void_p), n, C.byref(out)))
+    assert pa.api._g1_value(out) == cref.msm(pts, sc)
+
+
+def test_msm_full_size_trapdoor(ctx):
+    """2^20 points: commit(f) == f(tau) * G, uniform and skewed scalars."""
+    import plonk_amd as pa
+    n = 1 << 20
+    tau = P.synthetic_tau(20)
+    srs = pa.Srs.from_tau(tau, n - 1)
+    rng = np.random.default_rng(20)
+    G = curve.G1_GEN
+    for kind in ("uniform", "skewed"):
+        if kind == "uniform":
+            sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        else:
+            sc = pa.fr_to_array([0, 1, R_MOD - 1, 2])[rng.integers(0, 4, size=n)]
+        vals = pa.fr_from_array(sc)
+        out = pa._lib.G1()
+        ctx.check(pa._lib.lib.plonk_commit(ctx.h, srs.h, sc.ctypes.data_as(C.c_void_p), n, C.byref(out)))
+        assert pa.api._g1_value(out) == curve.to_affine(curve.scalar_mul(G, P.poly_eval(vals, tau))), kind
+
+
+# ------------------------------------------------------------------ quotient + prover
+def _oracle_case(cs, tau, blinding, pis):
+    class _S:
+        pass
+    srs = _S()
+    srs.tau, srs.max_degree, srs.g1_powers = tau, cs.n + 10, [None] * (cs.n + 11)
+    pk, vk, perm, dom = P.preprocess(cs, srs, use_trapdoor=True)
+    tr = {}
+    proof = P.prove(cs, pk, perm, dom, srs, pis, blinding, use_trapdoor=True, trace=tr)
+    return srs, pk, vk, perm, proof, tr
+
+
+def _gpu_case(cs, perm, tau):
+    import plonk_amd as pa
+    srs = pa.Srs.from_tau(tau, cs.n + 10)
+    pk = pa.ProvingKey(cs.n, cs.selectors(), [perm.s_sigma1_evals, perm.s_sigma2_evals, perm.s_sigma3_evals],
+                       perm.k1, perm.k2, cs.public_input_positions)
+    return srs, pk
+
+
+VK_KEYS = ("q_m", "q_l", "q_r", "q_o", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "rp42_pi", "rp0", "synthetic6", "synthetic10"])
+def test_prove_matches_oracle_bytes(ctx, name):
+    import plonk_amd as pa
+    bl = _rand(98, 11)
+    tau = _rand(99, 1)[0]
+    pis = []
+    if name == "c1":
+        cs = P.square_add_circuit()
+    elif name == "c2":
+        cs = P.range_proof_circuit(8, 255)
+    elif name == "rp42_pi":
+        cs, pis = P.range_proof_circuit(8, 42), [42]
+    elif name == "rp0":
+        cs = P.range_proof_circuit(8, 0)
+    else:
+        k = int(name[len("synthetic"):])
+        cs, bl = P.synthetic_circuit(k)
+        tau = P.synthetic_tau(k)
+    osrs, pk_o, vk_o, perm, proof_o, tr = _oracle_case(cs, tau, bl, pis)
+    srs, pk = _gpu_case(cs, perm, tau)
+    assert pk.commitments(srs) == [vk_o[k] for k in VK_KEYS]
+    for which, key in enumerate(("q_m", "q_l", "q_r", "q_o", "q_c", "s_sigma1", "s_sigma2", "s_sigma3", "l1")):
+        assert pk.poly(which) == getattr(pk_o, key)
+    proof = pa.Prover(cs.wire_values(), pk, srs).prove(pis, bl)
+    assert proof.to_dict() == proof_o
+    assert proof.to_bytes() == P.proof_to_bytes(proof_o)
+    assert proof.challenges(pis) == [tr[k] for k in ("beta", "gamma", "alpha", "zeta", "v", "u")]
+    assert P.verify(vk_o, osrs, proof.to_dict(), pis)
+    if pis:
+        assert not P.verify(vk_o, osrs, proof.to_dict(), [pis[0] + 1])  # verifier.rs:455-482
+
+
+def test_prove_golden_bytes(ctx):
+    import plonk_amd as pa
+    makers = {"c1_square_add": lambda: P.square_add_circuit(), "c2_range_proof_255": lambda: P.range_proof_circuit(8, 255),
+              "range_proof_42_pi": lambda: P.range_proof_circuit(8, 42)}
+    for e in golden("proofs.json"):
+        if e["name"].startswith("synthetic_2^"):
+            cs = P.synthetic_circuit(int(e["name"].split("^")[1]))[0]
+        else:
+            cs = makers[e["name"]]()
+        perm = P.Permutation(cs, offt.Domain(cs.n))
+        srs, pk = _gpu_case(cs, perm, int(e["tau"], 16))
+        pis = [int(x, 16) for x in e["public_inputs"]]
+        proof = pa.Prover(cs.wire_values(), pk, srs).prove(pis, [int(b, 16) for b in e["blinding"]])
+        assert proof.to_bytes().hex() == e["proof"], e["name"]
+        assert [curve.compress(p).hex() for p in pk.commitments(srs)] == e["vk"], e["name"]
+
+
+def test_quotient_entry_point_matches_oracle(ctx):
+    """plonk_quotient_3wire_dev against prover.rs:364-457,:497 restated (oracle trace)."""
+    import plonk_amd as pa
+    cs = P.range_proof_circuit(8, 77)
+    bl, tau = _rand(1, 11), 4242
+    osrs, pk_o, vk_o, perm, proof_o, tr = _oracle_case(cs, tau, bl, [])
+    srs, pk = _gpu_case(cs, perm, tau)
+    n4 = 4 * cs.n
+    bufs = []
+    for key in ("a", "b", "c", "z"):
+        d = ctx.alloc(n4 * 32)
+        ctx.upload(d, pa.fr_to_array(tr[key] + [0] * (n4 - len(tr[key]))))
+        bufs.append(d)
+    t = ctx.alloc(n4 * 32)
+    ch = [pa.api._fr_struct(tr[k]) for k in ("alpha", "beta", "gamma")]
+    ctx.check(pa._lib.lib.plonk_quotient_3wire_dev(ctx.h, pk.h, *bufs, None, *[C.byref(c) for c in ch], t))
+    got = pa.fr_from_array(ctx.download(t, n4 * 32).reshape(-1, 4))
+    assert got == tr["t"] + [0] * (n4 - len(tr["t"]))
+    for d in bufs + [t]:
+        ctx.free(d)
+
+
+def test_prover_error_behaviour(ctx):
+    """What panics in the reference returns PLONK_E_INVALID here."""
+    import plonk_amd as pa
+    cs = P.range_proof_circuit(8, 9)
+    perm = P.Permutation(cs, offt.Domain(cs.n))
+    srs, pk = _gpu_case(cs, perm, 5555)
+    a, b, c = cs.wire_values()
+    bad = list(a)
+    bad[3] = (bad[3] + 1) % R_MOD  # unsatisfied witness: t is not a polynomial of degree <= 3n+5
+    with pytest.raises(pa.PlonkError) as ei:
+        pa.Prover((bad, b, c), pk, srs).prove([], _rand(2, 11))
+    assert ei.value.code == pa._lib.PLONK_E_INVALID
+    small = pa.Srs.from_tau(5555, cs.n)  # SRS too short for the blinded polynomials (kzg.rs:232-238)
+    with pytest.raises(pa.PlonkError):
+        pa.Prover((a, b, c), pk, small).prove([], _rand(2, 11))
+    with pytest.raises(pa.PlonkError):
+        pa.Prover((a, b, c), pk, srs).prove([], _rand(2, 10))
+    with pytest.raises(pa.PlonkError):
+        pa.ProvingKey(12, cs.selectors(), [perm.s_sigma1_evals] * 3, 6, 7)
+    # a valid proof still comes out afterwards
+    assert len(pa.Prover((a, b, c), pk, srs).prove([], _rand(2, 11)).to_bytes()) == 624
+
+
+@pytest.mark.parametrize("k", [14, 16])
+def test_prove_large_golden(ctx, k):
+    """Synthetic 2^14 / 2^16-gate circuits (BASELINE config 3): byte-identical to the oracle's proof."""
+    import plonk_amd as pa
+    es = [e for e in golden("proofs.json") if e["name"] == "synthetic_2^%d" % k]
+    if not es:
+        pytest.skip("fixture for 2^%d not generated" % k)
+    e = es[0]
+    cs, bl = P.synthetic_circuit(k)
+    perm = P.Permutation(cs, offt.Domain(cs.n))
+    srs, pk = _gpu_case(cs, perm, int(e["tau"], 16))
+    proof = pa.Prover(cs.wire_values(), pk, srs).prove([], bl)
+    assert proof.to_bytes().hex() == e["proof"]
+    assert [curve.compress(p).hex() for p in pk.commitments(srs)] == e["vk"]
