@@ -19,33 +19,47 @@
 
 #include "common.hpp"
 #include "g1.cuh"
+#include "g1x.cuh"
 #include "msm.hpp"
 
 namespace plonk {
 
 static constexpr uint32_t BIG_BUCKET = 192;   // points; above this a bucket gets a workgroup
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
+static constexpr uint32_t ORDER_BINS = 256;   // bucket sizes 0..BIG_BUCKET, then one bin for "big"
+static constexpr uint32_t CHUNK_LOG = 2;      // buckets per lane in the running-sum step
 
-// ---- 1. digits ----
-__global__ __launch_bounds__(256) void msm_digits_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                          uint32_t W, uint32_t nb, int32_t* __restrict__ digits,
-                                                          uint32_t* __restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fr_t s = f_from_mont<FrP>(ld(scalars + i));
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; ++w) {
-        uint32_t raw = (s.l[0] & mask) + carry;
+// signed c-bit digits of a canonical scalar, least significant window first
+struct DigitIter {
+    fr_t s;
+    uint32_t c, mask, half, carry;
+    __device__ __forceinline__ DigitIter(const fr_t& scalar_mont, uint32_t c_) : c(c_) {
+        s = f_from_mont<FrP>(scalar_mont);
+        mask = (1u << c) - 1u;
+        half = 1u << (c - 1);
+        carry = 0;
+    }
+    __device__ __forceinline__ int32_t next() {
+        const uint32_t raw = (s.l[0] & mask) + carry;
         int32_t d;
         if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
         else { d = (int32_t)raw; carry = 0; }
-        digits[(size_t)w * n + i] = d;
-        if (d != 0) atomicAdd(&counts[(size_t)w * nb + (uint32_t)(d < 0 ? -d : d)], 1u);
-        // s >>= c
 #pragma unroll
         for (int k = 0; k < 7; ++k) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
         s.l[7] >>= c;
+        return d;
+    }
+};
+
+// ---- 1. histogram of (window, |digit|) ----
+__global__ __launch_bounds__(256) void msm_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                                                        uint32_t nb, uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DigitIter it(ld(scalars + i), c);
+    for (uint32_t w = 0; w < W; ++w) {
+        const int32_t d = it.next();
+        if (d != 0) atomicAdd(&counts[(size_t)w * nb + (uint32_t)(d < 0 ? -d : d)], 1u);
     }
 }
 
@@ -74,14 +88,15 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
 }
 
-// ---- 3. scatter ----
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const int32_t* __restrict__ digits, uint32_t n, uint32_t W,
+// ---- 3. scatter: digits are recomputed rather than stored ----
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
                                                            uint32_t nb, uint32_t* __restrict__ cursor,
                                                            uint32_t* __restrict__ sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    DigitIter it(ld(scalars + i), c);
     for (uint32_t w = 0; w < W; ++w) {
-        const int32_t d = digits[(size_t)w * n + i];
+        const int32_t d = it.next();
         if (d == 0) continue;
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
         const uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + mag], 1u);
@@ -89,124 +104,202 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const int32_t* __restr
     }
 }
 
-__device__ __forceinline__ g1_affine_t load_signed_point(const g1_affine_t* points, uint32_t entry) {
-    g1_affine_t p = ld_affine(points + (entry & ~SIGN_BIT));
-    if (entry & SIGN_BIT) p.y = f_neg<FqP>(p.y);  // (0,0) stays (0,0)
+// ---- 4. bucket order: buckets sorted by decreasing size, so the lanes of a wave run equally long ----
+__device__ __forceinline__ uint32_t order_bin(uint32_t cnt) {  // bin 0 = big buckets, then sizes BIG..0
+    return cnt > BIG_BUCKET ? 0u : 1u + (BIG_BUCKET - cnt);
+}
+__global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                              uint32_t total_buckets, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t h[ORDER_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total_buckets) {
+        const uint32_t nbk = nb - 1;
+        atomicAdd(&h[order_bin(counts[(size_t)(gid / nbk) * nb + gid % nbk + 1])], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void msm_order_scan_kernel(uint32_t* __restrict__ bins, uint32_t* __restrict__ n_big) {
+    __shared__ uint32_t part[ORDER_BINS];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t v = bins[tid];
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < ORDER_BINS; off <<= 1) {
+        uint32_t t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    bins[tid] = part[tid] - v;  // exclusive start of each bin
+    if (tid == 0) *n_big = v;
+}
+__global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                                 uint32_t total_buckets, uint32_t* __restrict__ bins,
+                                                                 uint32_t* __restrict__ order) {
+    __shared__ uint32_t h[ORDER_BINS];
+    __shared__ uint32_t base[ORDER_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bin = 0, rank = 0;
+    if (gid < total_buckets) {
+        const uint32_t nbk = nb - 1;
+        bin = order_bin(counts[(size_t)(gid / nbk) * nb + gid % nbk + 1]);
+        rank = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (gid < total_buckets) order[base[bin] + rank] = gid;
+}
+
+__device__ __forceinline__ AffX load_signed_point(const g1x_affine_t* points, uint32_t entry) {
+    AffX p = ld_affx(points + (entry & ~SIGN_BIT));
+    if (entry & SIGN_BIT) p.y = fqx_neg_y(p.y);
     return p;
 }
 
-// ---- 4a. small buckets: one lane per bucket ----
-__global__ __launch_bounds__(256) void msm_bucket_kernel(const g1_affine_t* __restrict__ points,
+// ---- 5a. small buckets: one lane per bucket, visited in size order (order[0..n_big) are the big ones) ----
+__global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __restrict__ points,
                                                           const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
-                                                          uint32_t total_buckets, g1_xyzz_t* __restrict__ buckets,
-                                                          uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_buckets) return;
+                                                          uint32_t total_buckets, const uint32_t* __restrict__ order,
+                                                          const uint32_t* __restrict__ n_big, g1x_xyzz_t* __restrict__ buckets) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x + *n_big;
+    if (slot >= total_buckets) return;
+    const uint32_t gid = order[slot];
     const uint32_t nbk = nb - 1;
     const uint32_t w = gid / nbk, b = gid % nbk + 1;
     const uint32_t cnt = counts[(size_t)w * nb + b];
-    g1_xyzz_t acc = xyzz_identity();
-    if (cnt > BIG_BUCKET) {
-        big_list[atomicAdd(big_count, 1u)] = gid;
-    } else {
-        const uint32_t* src = sorted + (size_t)w * n + offsets[(size_t)w * nb + b];
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const g1_affine_t p = load_signed_point(points, src[k]);
-            xyzz_madd(acc, p);
-        }
+    const uint32_t* src = sorted + (size_t)w * n + offsets[(size_t)w * nb + b];
+    PtX acc = ptx_identity();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const AffX p = load_signed_point(points, src[k]);
+        ptx_madd(acc, p);
     }
-    st_xyzz(buckets + gid, acc);
+    st_ptx(buckets + gid, acc);
 }
 
-// ---- 4b. big buckets: one workgroup per bucket ----
-__global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1_affine_t* __restrict__ points,
+// ---- 5b. big buckets: one workgroup per bucket ----
+__global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t* __restrict__ points,
                                                               const uint32_t* __restrict__ sorted,
                                                               const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
-                                                              const uint32_t* __restrict__ big_list,
-                                                              const uint32_t* __restrict__ big_count,
-                                                              g1_xyzz_t* __restrict__ buckets) {
-    __shared__ g1_xyzz_t red[256];
+                                                              const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ n_big,
+                                                              g1x_xyzz_t* __restrict__ buckets) {
+    __shared__ g1x_xyzz_t red[256];
     const uint32_t tid = threadIdx.x;
-    const uint32_t nbig = *big_count;
+    const uint32_t nbig = *n_big;
     for (uint32_t item = blockIdx.x; item < nbig; item += gridDim.x) {
-        const uint32_t gid = big_list[item];
+        const uint32_t gid = order[item];
         const uint32_t nbk = nb - 1;
         const uint32_t w = gid / nbk, b = gid % nbk + 1;
         const uint32_t cnt = counts[(size_t)w * nb + b];
         const uint32_t* src = sorted + (size_t)w * n + offsets[(size_t)w * nb + b];
-        g1_xyzz_t acc = xyzz_identity();
+        PtX acc = ptx_identity();
         for (uint32_t k = tid; k < cnt; k += 256) {
-            const g1_affine_t p = load_signed_point(points, src[k]);
-            xyzz_madd(acc, p);
+            const AffX p = load_signed_point(points, src[k]);
+            ptx_madd(acc, p);
         }
-        st_xyzz(&red[tid], acc);
+        st_ptx(&red[tid], acc);
         __syncthreads();
         for (uint32_t s = 128; s > 0; s >>= 1) {
             if (tid < s) {
-                const g1_xyzz_t o = ld_xyzz(&red[tid + s]);
-                xyzz_add(acc, o);
-                st_xyzz(&red[tid], acc);
+                const PtX o = ld_ptx(&red[tid + s]);
+                ptx_add(acc, o);
+                st_ptx(&red[tid], acc);
             }
             __syncthreads();
         }
-        if (tid == 0) st_xyzz(buckets + gid, acc);
+        if (tid == 0) st_ptx(buckets + gid, acc);
         __syncthreads();
     }
 }
 
-// ---- 5a. chunked running sums: lane (w, t) covers buckets b in (t*L, (t+1)*L] ----
-__global__ __launch_bounds__(256) void msm_chunk_reduce_kernel(const g1_xyzz_t* __restrict__ buckets, uint32_t nbk,
-                                                                uint32_t log_l, uint32_t chunks_per_window,
-                                                                uint32_t total_chunks, g1_xyzz_t* __restrict__ partial) {
+// ---- 6a. running sums over chunks of L = 2^CHUNK_LOG buckets: lane (w, t) covers b in (tL, (t+1)L]
+//          A_t = sum (b - tL) B_b,  R_t = sum B_b.   sum_b b B_b = sum_t A_t + L sum_t t R_t ----
+__global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __restrict__ buckets, uint32_t nbk,
+                                                         uint32_t chunks_per_window, uint32_t total_chunks,
+                                                         g1x_xyzz_t* __restrict__ A, g1x_xyzz_t* __restrict__ R) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_chunks) return;
     const uint32_t w = gid / chunks_per_window, t = gid % chunks_per_window;
-    const uint32_t L = 1u << log_l;
-    const g1_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << log_l);
-    g1_xyzz_t running = xyzz_identity(), acc = xyzz_identity();
-    for (uint32_t j = L; j-- > 0;) {
-        const g1_xyzz_t bj = ld_xyzz(B + j);
-        xyzz_add(running, bj);
-        xyzz_add(acc, running);
+    const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << CHUNK_LOG);
+    PtX running = ptx_identity(), acc = ptx_identity();
+    for (uint32_t j = 1u << CHUNK_LOG; j-- > 0;) {
+        const PtX bj = ld_ptx(B + j);
+        ptx_add(running, bj);
+        ptx_add(acc, running);
     }
-    // acc = sum (b - t*L) * B_b ; add (t*L) * running
-    const uint32_t k = t << log_l;
-    if (k != 0 && !xyzz_is_inf(running)) {
-        g1_xyzz_t r = xyzz_identity();
-        for (int bit = 31 - __clz(k); bit >= 0; --bit) {
-            r = xyzz_double(r);
-            if ((k >> bit) & 1u) xyzz_add(r, running);
-        }
-        xyzz_add(acc, r);
-    }
-    st_xyzz(partial + gid, acc);
+    st_ptx(A + gid, acc);
+    st_ptx(R + gid, running);
 }
 
-// ---- 5b. per-window tree over the chunk partials ----
-__global__ __launch_bounds__(256) void msm_window_reduce_kernel(const g1_xyzz_t* __restrict__ partial,
-                                                                 uint32_t chunks_per_window,
-                                                                 g1_xyzz_t* __restrict__ window_sums) {
-    __shared__ g1_xyzz_t red[256];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    g1_xyzz_t acc = xyzz_identity();
-    for (uint32_t k = tid; k < chunks_per_window; k += 256) {
-        const g1_xyzz_t o = ld_xyzz(partial + (size_t)w * chunks_per_window + k);
-        xyzz_add(acc, o);
+// ---- 6b. masked tree sums.  quantity q = 0: sum_t A_t;  q = i + 1: G_i = sum over chunks t with bit i
+//          set of R_t  (so that sum_t t R_t = sum_i 2^i G_i).  One workgroup sums `span` chunks. ----
+__global__ __launch_bounds__(256) void msm_tree_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
+                                                        uint32_t chunks_per_window, uint32_t span, uint32_t parts,
+                                                        g1x_xyzz_t* __restrict__ out) {
+    __shared__ g1x_xyzz_t red[256];
+    const uint32_t part = blockIdx.x % parts, q = (blockIdx.x / parts), w = blockIdx.y, tid = threadIdx.x;
+    const g1x_xyzz_t* src = (q == 0 ? A : R) + (size_t)w * chunks_per_window;
+    const uint32_t lo = part * span, hi = min(chunks_per_window, lo + span);
+    PtX acc = ptx_identity();
+    for (uint32_t t = lo + tid; t < hi; t += 256) {
+        if (q == 0 || ((t >> (q - 1)) & 1u)) {
+            const PtX o = ld_ptx(src + t);
+            ptx_add(acc, o);
+        }
     }
-    st_xyzz(&red[tid], acc);
+    st_ptx(&red[tid], acc);
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (tid < s) {
-            const g1_xyzz_t o = ld_xyzz(&red[tid + s]);
-            xyzz_add(acc, o);
-            st_xyzz(&red[tid], acc);
+            const PtX o = ld_ptx(&red[tid + s]);
+            ptx_add(acc, o);
+            st_ptx(&red[tid], acc);
         }
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(window_sums + w, acc);
+    if (tid == 0) st_ptx(out + ((size_t)w * gridDim.x / parts + q) * parts + part, acc);
+}
+
+// ---- 6c. sum the `parts` partials of each (window, quantity) and convert to the saturated form ----
+__global__ __launch_bounds__(64) void msm_final_kernel(const g1x_xyzz_t* __restrict__ partial, uint32_t parts,
+                                                        g1_xyzz_t* __restrict__ out) {
+    const uint32_t item = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    PtX acc = ptx_identity();
+    for (uint32_t k = 0; k < parts; ++k) {
+        const PtX o = ld_ptx(partial + (size_t)item * parts + k);
+        ptx_add(acc, o);
+    }
+    g1_xyzz_t r;
+    r.x = x_to_sat<FqX>(acc.x); r.y = x_to_sat<FqX>(acc.y); r.zz = x_to_sat<FqX>(acc.zz); r.zzz = x_to_sat<FqX>(acc.zzz);
+    st_xyzz(out + item, r);
+}
+
+// saturated affine -> x-form affine
+__global__ __launch_bounds__(256) void g1_to_xform_kernel(const g1_affine_t* __restrict__ in, uint32_t n,
+                                                           g1x_affine_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const g1_affine_t p = ld_affine(in + i);
+    AffX q;
+    if (affine_is_inf(p)) {
+        q.x = x_zero<FqX>();
+        q.y = x_zero<FqX>();
+    } else {
+        q.x = x_from_sat<FqX>(p.x);
+        q.y = x_from_sat<FqX>(p.y);
+    }
+    stx(&out[i].x, q.x);
+    stx(&out[i].y, q.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -223,67 +316,133 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
     return h;
 }
 
+// One in-flight MSM: its own stream and buffers, so that several commitments overlap on the device.
+struct MsmSlot {
+    hipStream_t stream = nullptr;
+    DevBuf<uint32_t> sorted, counts, offsets, cursor, order, bins;
+    DevBuf<g1x_xyzz_t> buckets, A, R, partial;
+    DevBuf<g1_xyzz_t> sums;
+    std::vector<g1_xyzz_t> host_sums;
+    uint32_t c = 0, W = 0, nq = 0, log_chunks = 0;
+    bool empty = true;
+    ~MsmSlot() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
 struct MsmWorkspace {
-    DevBuf<int32_t> digits;
-    DevBuf<uint32_t> sorted, counts, offsets, cursor, big_list, big_count;
-    DevBuf<g1_xyzz_t> buckets, partial, window_sums;
+    static constexpr int SLOTS = 3;
+    MsmSlot slot[SLOTS];
+    hipEvent_t ready = nullptr;
+    ~MsmWorkspace() { if (ready) (void)hipEventDestroy(ready); }
 };
 
 static MsmWorkspace* msm_workspace(Ctx* ctx) {
-    if (!ctx->msm_ws) ctx->msm_ws = std::shared_ptr<void>(new MsmWorkspace(), [](void* p) { delete static_cast<MsmWorkspace*>(p); });
+    if (!ctx->msm_ws) {
+        MsmWorkspace* ws = new MsmWorkspace();
+        ctx->msm_ws = std::shared_ptr<void>(ws, [](void* p) { delete static_cast<MsmWorkspace*>(p); });
+        for (auto& s : ws->slot) HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming));
+    }
     return static_cast<MsmWorkspace*>(ctx->msm_ws.get());
 }
 
-// Queues the whole MSM on the ctx stream and returns the affine result after one stream sync.
-host::G1AffineH msm_run(Ctx* ctx, const g1_affine_t* points_dev, const fr_t* scalars_dev, size_t n) {
-    host::G1AffineH ident;
-    ident.x = host::Fq::zero(); ident.y = host::Fq::zero(); ident.inf = true;
-    if (n == 0) return ident;
+// Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the slot
+// stream behind it).
+static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* points, const fr_t* scalars, size_t n) {
+    MsmSlot& s = ws->slot[si];
+    s.empty = n == 0;
+    if (n == 0) return;
     PLONK_REQUIRE(n < ((size_t)1 << 31), "msm: too many points");
-    MsmWorkspace* ws = msm_workspace(ctx);
     const uint32_t c = msm_window_bits(n);
     const uint32_t W = (256 + c - 1) / c;
     const uint32_t nbk = 1u << (c - 1), nb = nbk + 1;
     const uint32_t total_buckets = W * nbk;
-    const uint32_t log_l = std::min(3u, c - 1);
-    const uint32_t chunks = nbk >> log_l, total_chunks = W * chunks;
-    ws->digits.ensure((size_t)W * n);
-    ws->sorted.ensure((size_t)W * n);
-    ws->counts.ensure((size_t)W * nb);
-    ws->offsets.ensure((size_t)W * nb);
-    ws->cursor.ensure((size_t)W * nb);
-    ws->big_list.ensure(total_buckets);
-    ws->big_count.ensure(4);
-    ws->buckets.ensure(total_buckets);
-    ws->partial.ensure(total_chunks);
-    ws->window_sums.ensure(W);
-    hipStream_t st = ctx->stream;
-    HIP_CHECK(hipMemsetAsync(ws->counts.p, 0, (size_t)W * nb * sizeof(uint32_t), st));
-    HIP_CHECK(hipMemsetAsync(ws->big_count.p, 0, 16, st));
-    const uint32_t nblk = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3(nblk), dim3(256), 0, st, scalars_dev, (uint32_t)n, c, W, nb, ws->digits.p,
-                       ws->counts.p);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(W), dim3(1024), 0, st, ws->counts.p, nb, ws->offsets.p, ws->cursor.p);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, ws->digits.p, (uint32_t)n, W, nb, ws->cursor.p,
-                       ws->sorted.p);
-    hipLaunchKernelGGL(msm_bucket_kernel, dim3((total_buckets + 255) / 256), dim3(256), 0, st, points_dev, ws->sorted.p,
-                       ws->offsets.p, ws->counts.p, (uint32_t)n, nb, total_buckets, ws->buckets.p, ws->big_list.p,
-                       ws->big_count.p);
-    hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points_dev, ws->sorted.p, ws->offsets.p,
-                       ws->counts.p, (uint32_t)n, nb, ws->big_list.p, ws->big_count.p, ws->buckets.p);
-    hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, ws->buckets.p, nbk,
-                       log_l, chunks, total_chunks, ws->partial.p);
-    hipLaunchKernelGGL(msm_window_reduce_kernel, dim3(W), dim3(256), 0, st, ws->partial.p, chunks, ws->window_sums.p);
+    const uint32_t chunks = nbk >> CHUNK_LOG, total_chunks = W * chunks;
+    uint32_t log_chunks = 0;
+    while ((1u << log_chunks) < chunks) ++log_chunks;
+    const uint32_t nq = 1 + log_chunks;
+    const uint32_t span = 2048, parts = (chunks + span - 1) / span;
+    s.c = c; s.W = W; s.nq = nq; s.log_chunks = log_chunks;
+    s.sorted.ensure((size_t)W * n);
+    s.counts.ensure((size_t)W * nb);
+    s.offsets.ensure((size_t)W * nb);
+    s.cursor.ensure((size_t)W * nb);
+    s.order.ensure(total_buckets);
+    s.bins.ensure(ORDER_BINS + 4);
+    s.buckets.ensure(total_buckets);
+    s.A.ensure(total_chunks);
+    s.R.ensure(total_chunks);
+    s.partial.ensure((size_t)W * nq * parts);
+    s.sums.ensure((size_t)W * nq);
+    s.host_sums.resize((size_t)W * nq);
+    hipStream_t st = s.stream;
+    HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(st, ws->ready, 0));
+    HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)W * nb * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
+    const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
+    uint32_t* n_big = s.bins.p + ORDER_BINS;
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.counts.p);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(W), dim3(1024), 0, st, s.counts.p, nb, s.offsets.p, s.cursor.p);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.cursor.p, s.sorted.p);
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p);
+    hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p, s.order.p);
+    hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
+                       (uint32_t)n, nb, s.order.p, n_big, s.buckets.p);
+    hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
+                       (uint32_t)n, nb, total_buckets, s.order.p, n_big, s.buckets.p);
+    hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunks,
+                       total_chunks, s.A.p, s.R.p);
+    hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, W), dim3(256), 0, st, s.A.p, s.R.p, chunks, span, parts, s.partial.p);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(W * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
     HIP_CHECK(hipGetLastError());
-    std::vector<g1_xyzz_t> sums(W);
-    HIP_CHECK(hipMemcpyAsync(sums.data(), ws->window_sums.p, W * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    host::G1XyzzH acc = xyzz_to_host(sums[W - 1]);
-    for (int w = (int)W - 2; w >= 0; --w) {
-        for (uint32_t k = 0; k < c; ++k) acc = host::g1_double(acc);
-        acc = host::g1_add(acc, xyzz_to_host(sums[w]));
+    HIP_CHECK(hipMemcpyAsync(s.host_sums.data(), s.sums.p, (size_t)W * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
+}
+
+// Wait for slot `si` and combine on the host: S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w.
+static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
+    MsmSlot& s = ws->slot[si];
+    host::G1AffineH ident;
+    ident.x = host::Fq::zero(); ident.y = host::Fq::zero(); ident.inf = true;
+    if (s.empty) return ident;
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    host::G1XyzzH acc = host::g1_identity();
+    for (int w = (int)s.W - 1; w >= 0; --w) {
+        for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
+        const g1_xyzz_t* q = s.host_sums.data() + (size_t)w * s.nq;
+        host::G1XyzzH g = host::g1_identity();
+        for (int i = (int)s.log_chunks - 1; i >= 0; --i) {
+            g = host::g1_double(g);
+            g = host::g1_add(g, xyzz_to_host(q[1 + i]));
+        }
+        for (uint32_t k = 0; k < CHUNK_LOG; ++k) g = host::g1_double(g);
+        g = host::g1_add(g, xyzz_to_host(q[0]));
+        acc = host::g1_add(acc, g);
     }
     return host::g1_to_affine(acc);
+}
+
+host::G1AffineH msm_run(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* scalars_dev, size_t n) {
+    MsmWorkspace* ws = msm_workspace(ctx);
+    msm_enqueue(ctx, ws, 0, points_dev, scalars_dev, n);
+    return msm_collect(ws, 0);
+}
+
+// Up to MsmWorkspace::SLOTS independent MSMs against the same points, overlapped on the device.
+void msm_run_batch(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* const* scalars_dev, const size_t* n, int count,
+                   host::G1AffineH* out) {
+    MsmWorkspace* ws = msm_workspace(ctx);
+    for (int base = 0; base < count; base += MsmWorkspace::SLOTS) {
+        const int m = std::min(MsmWorkspace::SLOTS, count - base);
+        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k]);
+        for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
+    }
+}
+
+void g1_convert_to_xform(Ctx* ctx, const g1_affine_t* in, size_t n, g1x_affine_t* out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(g1_to_xform_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, in, (uint32_t)n, out);
+    HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,6 +499,9 @@ Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n) {
     g1_pack(pts, n, packed);
     s->points.alloc(n);
     if (n) HIP_CHECK(hipMemcpy(s->points.p, packed.data(), n * sizeof(g1_affine_t), hipMemcpyHostToDevice));
+    s->px.alloc(n);
+    g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return s.release();
 }
 
@@ -465,6 +627,8 @@ Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n) {
     hipLaunchKernelGGL(xyzz_to_affine_kernel, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, tmp.p, (uint32_t)n, ch,
                        prefix.p, s->points.p);
     HIP_CHECK(hipGetLastError());
+    s->px.alloc(n);
+    g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return s.release();
 }
