@@ -322,10 +322,14 @@ struct MsmSlot {
     DevBuf<uint32_t> sorted, counts, offsets, cursor, order, bins;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
-    std::vector<g1_xyzz_t> host_sums;
+    g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
+    size_t host_cap = 0;
     uint32_t c = 0, W = 0, nq = 0, log_chunks = 0;
     bool empty = true;
-    ~MsmSlot() { if (stream) (void)hipStreamDestroy(stream); }
+    ~MsmSlot() {
+        if (host_sums) (void)hipHostFree(host_sums);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 struct MsmWorkspace {
@@ -373,7 +377,12 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     s.R.ensure(total_chunks);
     s.partial.ensure((size_t)W * nq * parts);
     s.sums.ensure((size_t)W * nq);
-    s.host_sums.resize((size_t)W * nq);
+    if ((size_t)W * nq > s.host_cap) {
+        if (s.host_sums) (void)hipHostFree(s.host_sums);
+        s.host_sums = nullptr;
+        HIP_CHECK(hipHostMalloc((void**)&s.host_sums, (size_t)W * nq * sizeof(g1_xyzz_t), hipHostMallocDefault));
+        s.host_cap = (size_t)W * nq;
+    }
     hipStream_t st = s.stream;
     HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
     HIP_CHECK(hipStreamWaitEvent(st, ws->ready, 0));
@@ -396,7 +405,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, W), dim3(256), 0, st, s.A.p, s.R.p, chunks, span, parts, s.partial.p);
     hipLaunchKernelGGL(msm_final_kernel, dim3(W * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(s.host_sums.data(), s.sums.p, (size_t)W * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)W * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
 }
 
 // Wait for slot `si` and combine on the host: S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w.
@@ -409,7 +418,7 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     host::G1XyzzH acc = host::g1_identity();
     for (int w = (int)s.W - 1; w >= 0; --w) {
         for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
-        const g1_xyzz_t* q = s.host_sums.data() + (size_t)w * s.nq;
+        const g1_xyzz_t* q = s.host_sums + (size_t)w * s.nq;
         host::G1XyzzH g = host::g1_identity();
         for (int i = (int)s.log_chunks - 1; i >= 0; --i) {
             g = host::g1_double(g);

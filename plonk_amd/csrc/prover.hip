@@ -179,7 +179,7 @@ struct ProverWorkspace {
     DevBuf<fr_t> co;      // [4][n+8] blinded coefficient vectors a b c z
     DevBuf<fr_t> num, den, scr;  // [n]
     DevBuf<fr_t> tp;      // [3][n+8] t_lo t_mid t_hi (blinded)
-    DevBuf<fr_t> wnum, wq, tmp;  // [n+8]
+    DevBuf<fr_t> wnum, wq, wq2, tmp;  // [n+8]
     DevBuf<fr_t> evals;   // [8]
     DevBuf<fr_t> totals, partial;
     DevBuf<uint32_t> flag;
@@ -223,6 +223,38 @@ static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, 
     return g1_sum_affine(all.data(), all.size());
 }
 
+// Several commitments against the same SRS, overlapped on the device (independent MSMs on
+// separate streams).  Sharded runs exchange one partial sum per commitment.
+static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
+                         uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out) {
+    const fr_t* ptr[4];
+    size_t len[4];
+    const bool sharded = shard && shard->world > 1;
+    for (int k = 0; k < count; ++k) {
+        if (!sharded) {
+            if (lens[k] > srs->n) poly_nonzero_check(ctx, coeffs[k], (uint32_t)srs->n, (uint32_t)lens[k], flag_dev);
+            ptr[k] = coeffs[k];
+            len[k] = std::min(lens[k], srs->n);
+        } else {
+            const size_t lo = std::min(shard->lo, lens[k]), hi = std::min(shard->lo + srs->n, lens[k]);
+            ptr[k] = coeffs[k] + lo;
+            len[k] = hi - lo;
+        }
+    }
+    msm_run_batch(ctx, srs->px.p, ptr, len, count, out);
+    if (sharded) {
+        std::vector<plonk_g1> mine(count), all((size_t)count * shard->world);
+        for (int k = 0; k < count; ++k) g1_from_host(out[k], &mine[k]);
+        const int rc = shard->allgather(shard->user, mine.data(), sizeof(plonk_g1) * count, all.data());
+        if (rc != 0) throw Error(PLONK_E_INTERNAL, "commit: all-gather of the MSM partial sums failed");
+        std::vector<plonk_g1> col(shard->world);
+        for (int k = 0; k < count; ++k) {
+            for (uint32_t r = 0; r < shard->world; ++r) col[r] = all[(size_t)r * count + k];
+            out[k] = g1_sum_affine(col.data(), col.size());
+        }
+    }
+}
+
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
     ProverWorkspace* ws = prover_workspace(ctx);
     ws->flag.ensure(4);
@@ -250,7 +282,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     ProverWorkspace* ws = prover_workspace(ctx);
     ws->w4.ensure(5 * n4); ws->t.ensure(n4); ws->ev.ensure(3 * n); ws->co.ensure(4 * ns);
     ws->num.ensure(n); ws->den.ensure(n); ws->scr.ensure(n); ws->tp.ensure(3 * ns);
-    ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
+    ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->wq2.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
     hipStream_t st = ctx->stream;
     fr_h bl[11];
     for (int i = 0; i < 11; ++i) {
@@ -291,7 +323,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
         HIP_CHECK(hipMemcpyAsync(CO[k], W[k], (n + 2) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
     }
-    for (int k = 0; k < 3; ++k) comm[k] = commit_dev(ctx, srs, CO[k], n + 2, ws->flag.p, shard);
+    {
+        const fr_t* cp[3] = {CO[0], CO[1], CO[2]};
+        const size_t cl[3] = {n + 2, n + 2, n + 2};
+        commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm);
+    }
     tr.absorb_g1("a_comm", comm[0]);
     tr.absorb_g1("b_comm", comm[1]);
     tr.absorb_g1("c_comm", comm[2]);
@@ -344,9 +380,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     poly_poke(ctx, TP[1], 0, bl[9], true);              // t_mid -= b10
     poly_poke(ctx, TP[1], (uint32_t)n, bl[10], false);  // t_mid += b11 X^n
     poly_poke(ctx, TP[2], 0, bl[10], true);             // t_hi  -= b11
-    comm[4] = commit_dev(ctx, srs, TP[0], n + 1, ws->flag.p, shard);
-    comm[5] = commit_dev(ctx, srs, TP[1], n + 1, ws->flag.p, shard);
-    comm[6] = commit_dev(ctx, srs, TP[2], n + 6, ws->flag.p, shard);
+    {
+        const fr_t* cp[3] = {TP[0], TP[1], TP[2]};
+        const size_t cl[3] = {n + 1, n + 1, n + 6};
+        commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm + 4);
+    }
     check_flag(ctx, ws);
     tr.absorb_g1("t_lo_comm", comm[4]);
     tr.absorb_g1("t_mid_comm", comm[5]);
@@ -431,13 +469,14 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
-        comm[7] = commit_dev(ctx, srs, ws->wq.p, wlen - 1, ws->flag.p, shard);
         // W_{zeta omega} = (z - z_bar_omega) / (X - zeta omega)  (:815-816)
         HIP_CHECK(hipMemcpyAsync(ws->wnum.p, CO[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
         poly_poke(ctx, ws->wnum.p, 0, zw_bar, true);
-        HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
-        poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq.p, ws->totals);
-        comm[8] = commit_dev(ctx, srs, ws->wq.p, n + 2, ws->flag.p, shard);
+        HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
+        poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq2.p, ws->totals);
+        const fr_t* cp[2] = {ws->wq.p, ws->wq2.p};
+        const size_t cl[2] = {wlen - 1, n + 2};
+        commit_batch(ctx, srs, cp, cl, 2, ws->flag.p, shard, comm + 7);
         check_flag(ctx, ws);
     }
 
