@@ -316,9 +316,12 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
     return h;
 }
 
-// One in-flight MSM: its own stream and buffers, so that several commitments overlap on the device.
+// One in-flight MSM: its own buffers and events.  The three phases of an MSM run on three streams
+// shared by all slots -- sort (histogram, scan, scatter, bucket order: atomics and scattered stores),
+// buckets (integer-VALU bound) and tail (latency-bound reductions) -- so the sort of MSM k+1 and the
+// tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
-    hipStream_t stream = nullptr;
+    hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;
     DevBuf<uint32_t> sorted, counts, offsets, cursor, order, bins;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
@@ -328,28 +331,43 @@ struct MsmSlot {
     bool empty = true;
     ~MsmSlot() {
         if (host_sums) (void)hipHostFree(host_sums);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (sorted_ev) (void)hipEventDestroy(sorted_ev);
+        if (buckets_ev) (void)hipEventDestroy(buckets_ev);
+        if (done_ev) (void)hipEventDestroy(done_ev);
     }
 };
 
 struct MsmWorkspace {
     static constexpr int SLOTS = 3;
     MsmSlot slot[SLOTS];
+    hipStream_t sort_stream = nullptr, bucket_stream = nullptr, tail_stream = nullptr;
     hipEvent_t ready = nullptr;
-    ~MsmWorkspace() { if (ready) (void)hipEventDestroy(ready); }
+    ~MsmWorkspace() {
+        if (ready) (void)hipEventDestroy(ready);
+        if (sort_stream) (void)hipStreamDestroy(sort_stream);
+        if (bucket_stream) (void)hipStreamDestroy(bucket_stream);
+        if (tail_stream) (void)hipStreamDestroy(tail_stream);
+    }
 };
 
 static MsmWorkspace* msm_workspace(Ctx* ctx) {
     if (!ctx->msm_ws) {
         MsmWorkspace* ws = new MsmWorkspace();
         ctx->msm_ws = std::shared_ptr<void>(ws, [](void* p) { delete static_cast<MsmWorkspace*>(p); });
-        for (auto& s : ws->slot) HIP_CHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&ws->sort_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&ws->bucket_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&ws->tail_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming));
+        for (auto& s : ws->slot) {
+            HIP_CHECK(hipEventCreateWithFlags(&s.sorted_ev, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&s.buckets_ev, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&s.done_ev, hipEventDisableTiming));
+        }
     }
     return static_cast<MsmWorkspace*>(ctx->msm_ws.get());
 }
 
-// Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the slot
+// Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the sort
 // stream behind it).
 static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* points, const fr_t* scalars, size_t n) {
     MsmSlot& s = ws->slot[si];
@@ -383,29 +401,39 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
         HIP_CHECK(hipHostMalloc((void**)&s.host_sums, (size_t)W * nq * sizeof(g1_xyzz_t), hipHostMallocDefault));
         s.host_cap = (size_t)W * nq;
     }
-    hipStream_t st = s.stream;
+    const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
+    uint32_t* n_big = s.bins.p + ORDER_BINS;
+    // ---- sort phase ----
+    hipStream_t st = ws->sort_stream;
     HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
     HIP_CHECK(hipStreamWaitEvent(st, ws->ready, 0));
     HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)W * nb * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
-    const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
-    uint32_t* n_big = s.bins.p + ORDER_BINS;
     hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.counts.p);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(W), dim3(1024), 0, st, s.counts.p, nb, s.offsets.p, s.cursor.p);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.cursor.p, s.sorted.p);
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
     hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p, s.order.p);
+    HIP_CHECK(hipEventRecord(s.sorted_ev, st));
+    // ---- bucket phase ----
+    st = ws->bucket_stream;
+    HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
     hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        (uint32_t)n, nb, s.order.p, n_big, s.buckets.p);
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        (uint32_t)n, nb, total_buckets, s.order.p, n_big, s.buckets.p);
+    HIP_CHECK(hipEventRecord(s.buckets_ev, st));
+    // ---- tail phase ----
+    st = ws->tail_stream;
+    HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
     hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunks,
                        total_chunks, s.A.p, s.R.p);
     hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, W), dim3(256), 0, st, s.A.p, s.R.p, chunks, span, parts, s.partial.p);
     hipLaunchKernelGGL(msm_final_kernel, dim3(W * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)W * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(s.done_ev, st));
 }
 
 // Wait for slot `si` and combine on the host: S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w.
@@ -414,7 +442,7 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     host::G1AffineH ident;
     ident.x = host::Fq::zero(); ident.y = host::Fq::zero(); ident.inf = true;
     if (s.empty) return ident;
-    HIP_CHECK(hipStreamSynchronize(s.stream));
+    HIP_CHECK(hipEventSynchronize(s.done_ev));
     host::G1XyzzH acc = host::g1_identity();
     for (int w = (int)s.W - 1; w >= 0; --w) {
         for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
@@ -437,7 +465,7 @@ host::G1AffineH msm_run(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* sc
     return msm_collect(ws, 0);
 }
 
-// Up to MsmWorkspace::SLOTS independent MSMs against the same points, overlapped on the device.
+// Up to MsmWorkspace::SLOTS independent MSMs against the same points, pipelined on the device.
 void msm_run_batch(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out) {
     MsmWorkspace* ws = msm_workspace(ctx);
