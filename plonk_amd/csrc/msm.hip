@@ -340,13 +340,12 @@ struct MsmSlot {
 struct MsmWorkspace {
     static constexpr int SLOTS = 3;
     MsmSlot slot[SLOTS];
-    hipStream_t sort_stream = nullptr, bucket_stream = nullptr, tail_stream = nullptr;
+    hipStream_t sort_stream = nullptr, bucket_stream = nullptr;
     hipEvent_t ready = nullptr;
     ~MsmWorkspace() {
         if (ready) (void)hipEventDestroy(ready);
         if (sort_stream) (void)hipStreamDestroy(sort_stream);
         if (bucket_stream) (void)hipStreamDestroy(bucket_stream);
-        if (tail_stream) (void)hipStreamDestroy(tail_stream);
     }
 };
 
@@ -356,7 +355,6 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
         ctx->msm_ws = std::shared_ptr<void>(ws, [](void* p) { delete static_cast<MsmWorkspace*>(p); });
         HIP_CHECK(hipStreamCreateWithFlags(&ws->sort_stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&ws->bucket_stream, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&ws->tail_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming));
         for (auto& s : ws->slot) {
             HIP_CHECK(hipEventCreateWithFlags(&s.sorted_ev, hipEventDisableTiming));
@@ -369,7 +367,8 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
 
 // Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the sort
 // stream behind it).
-static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* points, const fr_t* scalars, size_t n) {
+static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* points, const fr_t* scalars, size_t n,
+                        bool tail_phase) {
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
     if (n == 0) return;
@@ -403,10 +402,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     }
     const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
     uint32_t* n_big = s.bins.p + ORDER_BINS;
-    // ---- sort phase ----
-    hipStream_t st = ws->sort_stream;
-    HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
-    HIP_CHECK(hipStreamWaitEvent(st, ws->ready, 0));
+    hipStream_t st;
+    if (!tail_phase) {
+    // ---- sort phase (the caller has ordered the sort stream behind the scalars) ----
+    st = ws->sort_stream;
     HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)W * nb * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.counts.p);
@@ -424,8 +423,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        (uint32_t)n, nb, total_buckets, s.order.p, n_big, s.buckets.p);
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
-    // ---- tail phase ----
-    st = ws->tail_stream;
+    return;
+    }
+    // ---- tail phase, on the ctx stream (idle while its commitments are in flight) ----
+    st = ctx->stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
     hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunks,
                        total_chunks, s.A.p, s.R.p);
@@ -460,9 +461,9 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
 }
 
 host::G1AffineH msm_run(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* scalars_dev, size_t n) {
-    MsmWorkspace* ws = msm_workspace(ctx);
-    msm_enqueue(ctx, ws, 0, points_dev, scalars_dev, n);
-    return msm_collect(ws, 0);
+    host::G1AffineH out;
+    msm_run_batch(ctx, points_dev, &scalars_dev, &n, 1, &out);
+    return out;
 }
 
 // Up to MsmWorkspace::SLOTS independent MSMs against the same points, pipelined on the device.
@@ -471,7 +472,10 @@ void msm_run_batch(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* const* 
     MsmWorkspace* ws = msm_workspace(ctx);
     for (int base = 0; base < count; base += MsmWorkspace::SLOTS) {
         const int m = std::min(MsmWorkspace::SLOTS, count - base);
-        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k]);
+        HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
+        HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
+        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k], false);
+        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k], true);
         for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
     }
 }
