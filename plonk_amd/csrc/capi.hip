@@ -231,17 +231,17 @@ int32_t plonk_commit(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeff
     PLONK_REQUIRE(len <= s->n, "commit: polynomial degree exceeds SRS max degree");
     DevBuf<fr_t> buf(len);
     if (len) HIP_CHECK(hipMemcpyAsync(buf.p, coeffs_host, len * sizeof(fr_t), hipMemcpyHostToDevice, C_->stream));
-    g1_from_host(msm_run(C_, s->px.p, buf.p, len), out);
+    g1_from_host(msm_run(C_, msm_points(s), buf.p, len), out);
     API_END()
 }
 
 int32_t plonk_msm(plonk_ctx* ctx, const plonk_g1* points_host, const plonk_fr* scalars_host, size_t n, plonk_g1* out) {
     if (!ctx || !out || (n && (!points_host || !scalars_host))) return PLONK_E_INVALID;
     API_BEGIN(ctx)
-    std::unique_ptr<Srs> tmp(srs_upload(C_, points_host, n));
+    std::unique_ptr<Srs> tmp(srs_upload(C_, points_host, n, /*with_table=*/false));
     DevBuf<fr_t> sc(n);
     if (n) HIP_CHECK(hipMemcpyAsync(sc.p, scalars_host, n * sizeof(fr_t), hipMemcpyHostToDevice, C_->stream));
-    g1_from_host(msm_run(C_, tmp->px.p, sc.p, n), out);
+    g1_from_host(msm_run(C_, msm_points(tmp.get()), sc.p, n), out);
     API_END()
 }
 

@@ -24,6 +24,21 @@ struct PtX {
 __device__ __forceinline__ fqx qmul(const fqx& a, const fqx& b) { return x_mul<FqX>(a, b); }
 __device__ __forceinline__ fqx qsqr(const fqx& a) { return x_sqr<FqX>(a); }
 
+// How a point operation multiplies.  MulInline expands every product in place: ~3.5 KB of code per
+// product, right for the bucket loop whose many waves share one instruction stream.  MulCall goes
+// through one out-of-line routine (operands and result in registers), so a whole point addition
+// stays a few KB: the reductions after the bucket phase run a handful of waves through long
+// dependent chains, and there instruction fetch of the expanded form costs more than the
+// arithmetic.
+struct MulInline {
+    static __device__ __forceinline__ fqx mul(const fqx& a, const fqx& b) { return x_mul<FqX>(a, b); }
+    static __device__ __forceinline__ fqx sqr(const fqx& a) { return x_sqr<FqX>(a); }
+};
+struct MulCall {
+    static __device__ __noinline__ fqx mul(fqx a, fqx b) { return x_mul<FqX>(a, b); }
+    static __device__ __forceinline__ fqx sqr(const fqx& a) { return mul(a, a); }
+};
+
 __device__ __forceinline__ bool ptx_is_inf(const PtX& p) { return x_limbs_zero<FqX>(p.zz); }
 __device__ __forceinline__ bool affx_is_inf(const AffX& p) { return x_limbs_zero<FqX>(p.x) && x_limbs_zero<FqX>(p.y); }
 __device__ __forceinline__ PtX ptx_identity() {
@@ -83,16 +98,17 @@ __device__ __forceinline__ void ptx_madd(PtX& acc, const AffX& q) {
 }
 
 // acc += q (add-2008-s: 12M + 2S)
+template <class M = MulInline>
 __device__ __forceinline__ void ptx_add(PtX& acc, const PtX& q) {
     if (ptx_is_inf(q)) return;
     if (ptx_is_inf(acc)) {
         acc = q;
         return;
     }
-    const fqx U1 = qmul(acc.x, q.zz);
-    const fqx U2 = qmul(q.x, acc.zz);
-    const fqx S1 = qmul(acc.y, q.zzz);
-    const fqx S2 = qmul(q.y, acc.zzz);
+    const fqx U1 = M::mul(acc.x, q.zz);
+    const fqx U2 = M::mul(q.x, acc.zz);
+    const fqx S1 = M::mul(acc.y, q.zzz);
+    const fqx S2 = M::mul(q.y, acc.zzz);
     const fqx P = x_sub<FqX, 2>(U2, U1);  // < 4p
     const fqx R = x_sub<FqX, 2>(S2, S1);
     if (x_is_zero16<FqX>(P)) {
@@ -100,15 +116,15 @@ __device__ __forceinline__ void ptx_add(PtX& acc, const PtX& q) {
         else acc = ptx_identity();
         return;
     }
-    const fqx PP = qsqr(P);
-    const fqx PPP = qmul(P, PP);
-    const fqx Q = qmul(U1, PP);
-    const fqx X3 = x_sub<FqX, 4>(x_sub<FqX, 2>(qsqr(R), PPP), x_add<FqX>(Q, Q));
-    const fqx Y3 = x_sub<FqX, 2>(qmul(R, x_sub<FqX, 8>(Q, X3)), qmul(S1, PPP));
+    const fqx PP = M::sqr(P);
+    const fqx PPP = M::mul(P, PP);
+    const fqx Q = M::mul(U1, PP);
+    const fqx X3 = x_sub<FqX, 4>(x_sub<FqX, 2>(M::sqr(R), PPP), x_add<FqX>(Q, Q));
+    const fqx Y3 = x_sub<FqX, 2>(M::mul(R, x_sub<FqX, 8>(Q, X3)), M::mul(S1, PPP));
     acc.x = X3;
     acc.y = Y3;
-    acc.zz = qmul(qmul(acc.zz, q.zz), PP);
-    acc.zzz = qmul(qmul(acc.zzz, q.zzz), PPP);
+    acc.zz = M::mul(M::mul(acc.zz, q.zz), PP);
+    acc.zzz = M::mul(M::mul(acc.zzz, q.zzz), PPP);
 }
 
 __device__ __forceinline__ AffX ld_affx(const g1x_affine_t* p) {

@@ -27,7 +27,7 @@ namespace plonk {
 static constexpr uint32_t BIG_BUCKET = 192;   // points; above this a bucket gets a workgroup
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr uint32_t ORDER_BINS = 256;   // bucket sizes 0..BIG_BUCKET, then one bin for "big"
-static constexpr uint32_t CHUNK_LOG = 2;      // buckets per lane in the running-sum step
+static constexpr uint32_t CHUNK_LOG = 3;      // buckets per lane in the running-sum step
 
 // signed c-bit digits of a canonical scalar, least significant window first
 struct DigitIter {
@@ -52,46 +52,99 @@ struct DigitIter {
 };
 
 // ---- 1. histogram of (window, |digit|) ----
+// `shared`: all windows feed ONE bucket set (the points of window w are then the precomputed
+// 2^(c w) P_i of the SRS table), otherwise window w has its own bucket set w.
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                        uint32_t nb, uint32_t* __restrict__ counts) {
+                                                        uint32_t nb, uint32_t shared, uint32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DigitIter it(ld(scalars + i), c);
     for (uint32_t w = 0; w < W; ++w) {
         const int32_t d = it.next();
-        if (d != 0) atomicAdd(&counts[(size_t)w * nb + (uint32_t)(d < 0 ? -d : d)], 1u);
+        if (d != 0) atomicAdd(&counts[(size_t)(shared ? 0u : w) * nb + (uint32_t)(d < 0 ? -d : d)], 1u);
     }
 }
 
-// ---- 2. scan (one workgroup of 1024 lanes per window) ----
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
-                                                         uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t part[1024];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    const uint32_t per = (nb + 1023) / 1024;
-    const uint32_t lo = min(nb, tid * per), hi = min(nb, lo + per);
+// ---- 2. exclusive scan of the counts of every bucket set, in tiles of SCAN_TILE entries:
+//         tile sums -> scan of the tile sums (one workgroup per set) -> scan inside each tile ----
+constexpr uint32_t SCAN_TILE = 4096;   // 256 lanes x 16 consecutive entries
+
+__global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
+                                                              uint32_t tiles, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t part[256];
+    const uint32_t set = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+    const uint32_t* src = counts + (size_t)set * nb;
     uint32_t sum = 0;
-    for (uint32_t k = lo; k < hi; ++k) sum += counts[(size_t)w * nb + k];
+    for (uint32_t k = tile * SCAN_TILE + tid; k < min(nb, (tile + 1) * SCAN_TILE); k += 256) sum += src[k];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) part[tid] += part[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) tile_sums[blockIdx.x] = part[0];
+}
+
+__global__ __launch_bounds__(1024) void msm_scan_sums_kernel(uint32_t* __restrict__ tile_sums, uint32_t tiles) {
+    __shared__ uint32_t part[1024];
+    const uint32_t set = blockIdx.x, tid = threadIdx.x;
+    uint32_t* v = tile_sums + (size_t)set * tiles;
+    const uint32_t per = (tiles + 1023) / 1024;
+    const uint32_t lo = min(tiles, tid * per), hi = min(tiles, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += v[k];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = tid >= off ? part[tid - off] : 0;
+        uint32_t t = tid >= off ? part[tid - off] : 0;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += t;
         __syncthreads();
     }
     uint32_t run = part[tid] - sum;  // exclusive
     for (uint32_t k = lo; k < hi; ++k) {
-        offsets[(size_t)w * nb + k] = run;
-        cursor[(size_t)w * nb + k] = run;
-        run += counts[(size_t)w * nb + k];
+        const uint32_t t = v[k];
+        v[k] = run;
+        run += t;
+    }
+}
+
+__global__ __launch_bounds__(256) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t tiles,
+                                                        const uint32_t* __restrict__ tile_sums,
+                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t part[256];
+    const uint32_t set = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+    const size_t base = (size_t)set * nb;
+    const uint32_t lo = min(nb, tile * SCAN_TILE + tid * 16), hi = min(nb, lo + 16);
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        v[k] = lo + k < hi ? counts[base + lo + k] : 0u;
+        sum += v[k];
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = tile_sums[blockIdx.x] + part[tid] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        if (lo + k < hi) {
+            offsets[base + lo + k] = run;
+            cursor[base + lo + k] = run;
+        }
+        run += v[k];
     }
 }
 
 // ---- 3. scatter: digits are recomputed rather than stored ----
 __global__ __launch_bounds__(256) void msm_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                           uint32_t nb, uint32_t* __restrict__ cursor,
-                                                           uint32_t* __restrict__ sorted) {
+                                                           uint32_t nb, uint32_t shared, uint32_t level_stride,
+                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DigitIter it(ld(scalars + i), c);
@@ -99,8 +152,10 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const fr_t* __restrict
         const int32_t d = it.next();
         if (d == 0) continue;
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        const uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + mag], 1u);
-        sorted[(size_t)w * n + pos] = i | (d < 0 ? SIGN_BIT : 0u);
+        const uint32_t set = shared ? 0u : w;
+        const uint32_t pos = atomicAdd(&cursor[(size_t)set * nb + mag], 1u);
+        const uint32_t point = shared ? w * level_stride + i : i;   // row w of the SRS table
+        sorted[(size_t)set * n + pos] = point | (d < 0 ? SIGN_BIT : 0u);
     }
 }
 
@@ -208,10 +263,11 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
         }
         st_ptx(&red[tid], acc);
         __syncthreads();
+#pragma unroll 1
         for (uint32_t s = 128; s > 0; s >>= 1) {
             if (tid < s) {
                 const PtX o = ld_ptx(&red[tid + s]);
-                ptx_add(acc, o);
+                ptx_add<MulCall>(acc, o);
                 st_ptx(&red[tid], acc);
             }
             __syncthreads();
@@ -231,54 +287,64 @@ __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __rest
     const uint32_t w = gid / chunks_per_window, t = gid % chunks_per_window;
     const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << CHUNK_LOG);
     PtX running = ptx_identity(), acc = ptx_identity();
+#pragma unroll 1
     for (uint32_t j = 1u << CHUNK_LOG; j-- > 0;) {
         const PtX bj = ld_ptx(B + j);
-        ptx_add(running, bj);
-        ptx_add(acc, running);
+        ptx_add<MulCall>(running, bj);
+        ptx_add<MulCall>(acc, running);
     }
     st_ptx(A + gid, acc);
     st_ptx(R + gid, running);
 }
 
-// ---- 6b. masked tree sums.  quantity q = 0: sum_t A_t;  q = i + 1: G_i = sum over chunks t with bit i
-//          set of R_t  (so that sum_t t R_t = sum_i 2^i G_i).  One workgroup sums `span` chunks. ----
-__global__ __launch_bounds__(256) void msm_tree_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
-                                                        uint32_t chunks_per_window, uint32_t span, uint32_t parts,
-                                                        g1x_xyzz_t* __restrict__ out) {
-    __shared__ g1x_xyzz_t red[256];
-    const uint32_t part = blockIdx.x % parts, q = (blockIdx.x / parts), w = blockIdx.y, tid = threadIdx.x;
-    const g1x_xyzz_t* src = (q == 0 ? A : R) + (size_t)w * chunks_per_window;
-    const uint32_t lo = part * span, hi = min(chunks_per_window, lo + span);
-    PtX acc = ptx_identity();
-    for (uint32_t t = lo + tid; t < hi; t += 256) {
-        if (q == 0 || ((t >> (q - 1)) & 1u)) {
-            const PtX o = ld_ptx(src + t);
-            ptx_add(acc, o);
-        }
-    }
+// sum of the 256 lanes' points through LDS; the result is in lane 0's acc
+__device__ __forceinline__ void block_sum(PtX& acc, g1x_xyzz_t* red, uint32_t tid, uint32_t lanes) {
     st_ptx(&red[tid], acc);
     __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
+#pragma unroll 1
+    for (uint32_t s = lanes >> 1; s > 0; s >>= 1) {
         if (tid < s) {
             const PtX o = ld_ptx(&red[tid + s]);
-            ptx_add(acc, o);
+            ptx_add<MulCall>(acc, o);
             st_ptx(&red[tid], acc);
         }
         __syncthreads();
     }
-    if (tid == 0) st_ptx(out + ((size_t)w * gridDim.x / parts + q) * parts + part, acc);
 }
 
-// ---- 6c. sum the `parts` partials of each (window, quantity) and convert to the saturated form ----
+// ---- 6b. tree sums.  quantity q = 0: sum_t A_t;  q = i + 1: G_i = sum of R_t over the chunks t with
+//          bit i set (so that sum_t t R_t = sum_i 2^i G_i); only those chunks are visited.  Workgroup
+//          (q, part) sums its share of the chunks. ----
+__global__ __launch_bounds__(256) void msm_tree_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
+                                                        uint32_t chunks_per_window, uint32_t parts, uint32_t nq,
+                                                        g1x_xyzz_t* __restrict__ out) {
+    __shared__ g1x_xyzz_t red[256];
+    const uint32_t part = blockIdx.x % parts, q = blockIdx.x / parts, w = blockIdx.y, tid = threadIdx.x;
+    const g1x_xyzz_t* src = (q == 0 ? A : R) + (size_t)w * chunks_per_window;
+    const uint32_t count = q == 0 ? chunks_per_window : chunks_per_window >> 1;
+    const uint32_t span = (count + parts - 1) / parts;
+    const uint32_t lo = min(count, part * span), hi = min(count, lo + span);
+    const uint32_t bit = q == 0 ? 0u : q - 1u;
+    PtX acc = ptx_identity();
+#pragma unroll 1
+    for (uint32_t k = lo + tid; k < hi; k += 256) {
+        // q > 0: the k-th chunk index with bit `bit` set
+        const uint32_t t = q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
+        const PtX o = ld_ptx(src + t);
+        ptx_add<MulCall>(acc, o);
+    }
+    block_sum(acc, red, tid, 256);
+    if (tid == 0) st_ptx(out + ((size_t)w * nq + q) * parts + part, acc);
+}
+
+// ---- 6c. sum the `parts` (<= 64) partials of each (window, quantity) and convert to the saturated form ----
 __global__ __launch_bounds__(64) void msm_final_kernel(const g1x_xyzz_t* __restrict__ partial, uint32_t parts,
                                                         g1_xyzz_t* __restrict__ out) {
-    const uint32_t item = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    PtX acc = ptx_identity();
-    for (uint32_t k = 0; k < parts; ++k) {
-        const PtX o = ld_ptx(partial + (size_t)item * parts + k);
-        ptx_add(acc, o);
-    }
+    __shared__ g1x_xyzz_t red[64];
+    const uint32_t item = blockIdx.x, tid = threadIdx.x;
+    PtX acc = tid < parts ? ld_ptx(partial + (size_t)item * parts + tid) : ptx_identity();
+    block_sum(acc, red, tid, 64);
+    if (tid != 0) return;
     g1_xyzz_t r;
     r.x = x_to_sat<FqX>(acc.x); r.y = x_to_sat<FqX>(acc.y); r.zz = x_to_sat<FqX>(acc.zz); r.zzz = x_to_sat<FqX>(acc.zzz);
     st_xyzz(out + item, r);
@@ -322,7 +388,7 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
 // tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
     hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;
-    DevBuf<uint32_t> sorted, counts, offsets, cursor, order, bins;
+    DevBuf<uint32_t> sorted, counts, offsets, cursor, tile_sums, order, bins;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
@@ -367,38 +433,45 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
 
 // Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the sort
 // stream behind it).
-static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* points, const fr_t* scalars, size_t n,
+static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts, const fr_t* scalars, size_t n,
                         bool tail_phase) {
+    const g1x_affine_t* points = pts.px;
+    // the table pays once the shared bucket set (2^(table_c-1) buckets) is reasonably full
+    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 4)) != 0) ? 1u : 0u;
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
     if (n == 0) return;
     PLONK_REQUIRE(n < ((size_t)1 << 31), "msm: too many points");
-    const uint32_t c = msm_window_bits(n);
+    const uint32_t c = shared ? pts.table_c : msm_window_bits(n);
     const uint32_t W = (256 + c - 1) / c;
+    const uint32_t S = shared ? 1u : W;   // bucket sets
     const uint32_t nbk = 1u << (c - 1), nb = nbk + 1;
-    const uint32_t total_buckets = W * nbk;
-    const uint32_t chunks = nbk >> CHUNK_LOG, total_chunks = W * chunks;
+    const uint32_t total_buckets = S * nbk;
+    const uint32_t chunks = nbk >> CHUNK_LOG, total_chunks = S * chunks;
     uint32_t log_chunks = 0;
     while ((1u << log_chunks) < chunks) ++log_chunks;
     const uint32_t nq = 1 + log_chunks;
-    const uint32_t span = 2048, parts = (chunks + span - 1) / span;
-    s.c = c; s.W = W; s.nq = nq; s.log_chunks = log_chunks;
+    const uint32_t parts = std::max(1u, chunks / 2048);
+    PLONK_REQUIRE(parts <= 64, "msm: window too wide for the reduction");
+    s.c = c; s.W = S; s.nq = nq; s.log_chunks = log_chunks;
     s.sorted.ensure((size_t)W * n);
-    s.counts.ensure((size_t)W * nb);
-    s.offsets.ensure((size_t)W * nb);
-    s.cursor.ensure((size_t)W * nb);
+    s.counts.ensure((size_t)S * nb);
+    s.offsets.ensure((size_t)S * nb);
+    s.cursor.ensure((size_t)S * nb);
+    const uint32_t tiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
+    s.tile_sums.ensure((size_t)S * tiles);
     s.order.ensure(total_buckets);
     s.bins.ensure(ORDER_BINS + 4);
     s.buckets.ensure(total_buckets);
     s.A.ensure(total_chunks);
     s.R.ensure(total_chunks);
-    s.partial.ensure((size_t)W * nq * parts);
-    s.sums.ensure((size_t)W * nq);
-    if ((size_t)W * nq > s.host_cap) {
+    s.partial.ensure((size_t)S * nq * parts);
+    s.sums.ensure((size_t)S * nq);
+    if ((size_t)S * nq > s.host_cap) {
         if (s.host_sums) (void)hipHostFree(s.host_sums);
         s.host_sums = nullptr;
-        HIP_CHECK(hipHostMalloc((void**)&s.host_sums, (size_t)W * nq * sizeof(g1_xyzz_t), hipHostMallocDefault));
-        s.host_cap = (size_t)W * nq;
+        HIP_CHECK(hipHostMalloc((void**)&s.host_sums, (size_t)S * nq * sizeof(g1_xyzz_t), hipHostMallocDefault));
+        s.host_cap = (size_t)S * nq;
     }
     const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
     uint32_t* n_big = s.bins.p + ORDER_BINS;
@@ -406,11 +479,15 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     if (!tail_phase) {
     // ---- sort phase (the caller has ordered the sort stream behind the scalars) ----
     st = ws->sort_stream;
-    HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)W * nb * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)S * nb * sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.counts.p);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(W), dim3(1024), 0, st, s.counts.p, nb, s.offsets.p, s.cursor.p);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, s.cursor.p, s.sorted.p);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, shared, s.counts.p);
+    hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(S * tiles), dim3(256), 0, st, s.counts.p, nb, tiles, s.tile_sums.p);
+    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(S), dim3(1024), 0, st, s.tile_sums.p, tiles);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(S * tiles), dim3(256), 0, st, s.counts.p, nb, tiles, s.tile_sums.p, s.offsets.p,
+                       s.cursor.p);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, shared,
+                       (uint32_t)pts.level_stride, s.cursor.p, s.sorted.p);
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
     hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p, s.order.p);
@@ -430,10 +507,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const g1x_affine_t* 
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
     hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunks,
                        total_chunks, s.A.p, s.R.p);
-    hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, W), dim3(256), 0, st, s.A.p, s.R.p, chunks, span, parts, s.partial.p);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(W * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
+    hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, S), dim3(256), 0, st, s.A.p, s.R.p, chunks, parts, nq, s.partial.p);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(S * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)W * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)S * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(s.done_ev, st));
 }
 
@@ -446,7 +523,8 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     HIP_CHECK(hipEventSynchronize(s.done_ev));
     host::G1XyzzH acc = host::g1_identity();
     for (int w = (int)s.W - 1; w >= 0; --w) {
-        for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
+        if (w != (int)s.W - 1)
+            for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
         const g1_xyzz_t* q = s.host_sums + (size_t)w * s.nq;
         host::G1XyzzH g = host::g1_identity();
         for (int i = (int)s.log_chunks - 1; i >= 0; --i) {
@@ -460,22 +538,23 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     return host::g1_to_affine(acc);
 }
 
-host::G1AffineH msm_run(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* scalars_dev, size_t n) {
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n) {
     host::G1AffineH out;
-    msm_run_batch(ctx, points_dev, &scalars_dev, &n, 1, &out);
+    msm_run_batch(ctx, pts, &scalars_dev, &n, 1, &out);
     return out;
 }
 
 // Up to MsmWorkspace::SLOTS independent MSMs against the same points, pipelined on the device.
-void msm_run_batch(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* const* scalars_dev, const size_t* n, int count,
+void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out) {
+    for (int k = 0; k < count; ++k) PLONK_REQUIRE(n[k] <= pts.level_stride, "msm: more scalars than points");
     MsmWorkspace* ws = msm_workspace(ctx);
     for (int base = 0; base < count; base += MsmWorkspace::SLOTS) {
         const int m = std::min(MsmWorkspace::SLOTS, count - base);
         HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
         HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
-        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k], false);
-        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, points_dev, scalars_dev[base + k], n[base + k], true);
+        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], false);
+        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], true);
         for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
     }
 }
@@ -523,7 +602,61 @@ void g1_from_host(const host::G1AffineH& a, plonk_g1* out) {
     memcpy(out->y, a.y.l, 48);
 }
 
-Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n) {
+// c doublings of every point: level w of the window table from level w-1
+__global__ __launch_bounds__(256) void g1_shift_level_kernel(const g1_affine_t* __restrict__ in, uint32_t n, uint32_t c,
+                                                              g1_xyzz_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const g1_affine_t p = ld_affine(in + i);
+    g1_xyzz_t acc = xyzz_double_affine(p);
+    for (uint32_t k = 1; k < c; ++k) acc = xyzz_double(acc);
+    st_xyzz(out + i, acc);
+}
+
+static void xyzz_to_affine(Ctx* ctx, const g1_xyzz_t* in, size_t n, fq_t* prefix, g1_affine_t* out);
+
+uint32_t msm_table_bits(size_t n) {
+    // one shared bucket set: aim at ~26-32 points per bucket, W n / 2^(c-1) with W = ceil(256/c)
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    return std::max(12u, std::min(21u, lg));
+}
+
+// Builds srs->px as the window table [W][n]: row w holds 2^(c w) P_i in x-form.  With the table
+// every window of a scalar feeds the same bucket set, so an MSM reduces 2^(c-1) buckets once
+// instead of W times, and c can grow to log2(n).  Costs W x the SRS in HBM (1.75 GB at n = 2^20).
+static void srs_build_points(Ctx* ctx, Srs* s, bool with_table) {
+    const size_t n = s->n;
+    s->table_c = 0;
+    s->levels = 1;
+    if (!with_table || n < MSM_TABLE_MIN_POINTS) {
+        s->px.alloc(n);
+        g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    const uint32_t c = msm_table_bits(n), W = (256 + c - 1) / c;
+    PLONK_REQUIRE((size_t)W * n < ((size_t)1 << 31), "srs: window table too large");
+    s->px.alloc((size_t)W * n);
+    g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
+    DevBuf<g1_affine_t> cur(n), nxt(n);
+    DevBuf<g1_xyzz_t> tmp(n);
+    DevBuf<fq_t> prefix(n);
+    HIP_CHECK(hipMemcpyAsync(cur.p, s->points.p, n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, ctx->stream));
+    for (uint32_t w = 1; w < W; ++w) {
+        hipLaunchKernelGGL(g1_shift_level_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, cur.p,
+                           (uint32_t)n, c, tmp.p);
+        xyzz_to_affine(ctx, tmp.p, n, prefix.p, nxt.p);
+        g1_convert_to_xform(ctx, nxt.p, n, s->px.p + (size_t)w * n);
+        std::swap(cur.p, nxt.p);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    s->table_c = c;
+    s->levels = W;
+}
+
+Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n, bool with_table) {
     for (size_t i = 0; i < n; ++i) {
         if (pts[i].infinity) continue;
         host::G1AffineH a;
@@ -540,9 +673,7 @@ Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n) {
     g1_pack(pts, n, packed);
     s->points.alloc(n);
     if (n) HIP_CHECK(hipMemcpy(s->points.p, packed.data(), n * sizeof(g1_affine_t), hipMemcpyHostToDevice));
-    s->px.alloc(n);
-    g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    srs_build_points(ctx, s.get(), with_table);
     return s.release();
 }
 
@@ -648,7 +779,14 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_kernel(const g1_xyzz_t* __
     }
 }
 
-Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n) {
+static void xyzz_to_affine(Ctx* ctx, const g1_xyzz_t* in, size_t n, fq_t* prefix, g1_affine_t* out) {
+    const uint32_t ch = 16;
+    const uint32_t lanes = (uint32_t)((n + ch - 1) / ch);
+    hipLaunchKernelGGL(xyzz_to_affine_kernel, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, in, (uint32_t)n, ch,
+                       prefix, out);
+}
+
+Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n, bool with_table) {
     PLONK_REQUIRE(n < ((size_t)1 << 31), "srs: too many points");
     std::unique_ptr<Srs> s(new Srs());
     s->device = ctx->device;
@@ -663,14 +801,9 @@ Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n) {
     const uint32_t nblk = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(srs_powers_kernel, dim3(nblk), dim3(256), 0, ctx->stream, to_dev(tau), (uint64_t)first, (uint32_t)n,
                        table_dev.p, tmp.p);
-    const uint32_t ch = 16;
-    const uint32_t lanes = (uint32_t)((n + ch - 1) / ch);
-    hipLaunchKernelGGL(xyzz_to_affine_kernel, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, tmp.p, (uint32_t)n, ch,
-                       prefix.p, s->points.p);
+    xyzz_to_affine(ctx, tmp.p, n, prefix.p, s->points.p);
     HIP_CHECK(hipGetLastError());
-    s->px.alloc(n);
-    g1_convert_to_xform(ctx, s->points.p, n, s->px.p);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    srs_build_points(ctx, s.get(), with_table);
     return s.release();
 }
 

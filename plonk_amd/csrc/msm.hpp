@@ -11,16 +11,31 @@ struct Srs {
     int device = 0;
     size_t n = 0;
     DevBuf<g1_affine_t> points;   // saturated Montgomery (x, y): the ABI image
-    DevBuf<g1x_affine_t> px;      // the same points in the radix-2^29 form the MSM kernels use
+    DevBuf<g1x_affine_t> px;      // radix-2^29 form for the MSM kernels: `levels` rows of n points,
+                                  // row w = 2^(table_c w) P_i (a single row when table_c == 0)
+    uint32_t table_c = 0;         // window width the table was built for, 0 = no table
+    uint32_t levels = 1;
 };
 
+// What an MSM reads its bases from.
+struct MsmPoints {
+    const g1x_affine_t* px;
+    size_t level_stride;          // points per table row (= Srs::n)
+    uint32_t table_c;             // 0: plain Pippenger, one bucket set per window
+};
+inline MsmPoints msm_points(const Srs* s) { return MsmPoints{s->px.p, s->n, s->table_c}; }
+
+// SRS sizes from which the window table is built (below it the per-window bucket sets are cheap).
+constexpr size_t MSM_TABLE_MIN_POINTS = (size_t)1 << 14;
+
 uint32_t msm_window_bits(size_t n);
-host::G1AffineH msm_run(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* scalars_dev, size_t n);
-void msm_run_batch(Ctx* ctx, const g1x_affine_t* points_dev, const fr_t* const* scalars_dev, const size_t* n, int count,
+uint32_t msm_table_bits(size_t n);
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n);
+void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out);
 void g1_convert_to_xform(Ctx* ctx, const g1_affine_t* in, size_t n, g1x_affine_t* out);
-Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n);
-Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n);
+Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n, bool with_table = true);
+Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n, bool with_table = true);
 void g1_unpack(const g1_affine_t& in, plonk_g1* out);
 void g1_from_host(const host::G1AffineH& a, plonk_g1* out);
 

@@ -210,11 +210,11 @@ static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, 
     if (!shard || shard->world <= 1) {
         size_t m = std::min(len, srs->n);
         if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
-        return msm_run(ctx, srs->px.p, coeffs, m);
+        return msm_run(ctx, msm_points(srs), coeffs, m);
     }
     // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
     const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
-    host::G1AffineH part = msm_run(ctx, srs->px.p, coeffs + lo, hi - lo);
+    host::G1AffineH part = msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo);
     plonk_g1 mine;
     g1_from_host(part, &mine);
     std::vector<plonk_g1> all(shard->world);
@@ -241,7 +241,7 @@ static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, co
             len[k] = hi - lo;
         }
     }
-    msm_run_batch(ctx, srs->px.p, ptr, len, count, out);
+    msm_run_batch(ctx, msm_points(srs), ptr, len, count, out);
     if (sharded) {
         std::vector<plonk_g1> mine(count), all((size_t)count * shard->world);
         for (int k = 0; k < count; ++k) g1_from_host(out[k], &mine[k]);

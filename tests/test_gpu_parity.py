@@ -192,6 +192,11 @@ def test_msm_matches_c_restatement(ctx, log_n):
     out = pa._lib.G1()
     ctx.check(pa._lib.lib.plonk_commit(ctx.h, srs.h, sc.ctypes.data_as(C.c_void_p), n, C.byref(out)))
     assert pa.api._g1_value(out) == cref.msm(pts, sc)
+    # shorter polynomials against the same SRS: below and above the size from which the
+    # window table of the SRS is used
+    for m in (5, 1000, 1 << (log_n - 4), 5000, n - 3):
+        ctx.check(pa._lib.lib.plonk_commit(ctx.h, srs.h, sc.ctypes.data_as(C.c_void_p), m, C.byref(out)))
+        assert pa.api._g1_value(out) == cref.msm(pts[:m], sc[:m]), m
 
 
 def test_msm_full_size_trapdoor(ctx):
