@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "fieldx.cuh"
 
 namespace plonk {
 
@@ -24,14 +25,32 @@ static constexpr int NTT_TILE_LOG = 11;      // elements per LDS tile = 2^11 (64
 static constexpr int NTT_SUBTW_LOG = 11;     // sub_tw holds w_{2^11}^j, j < 2^10
 static constexpr int NTT_THREADS = 256;
 
+// Arithmetic runs in the radix-2^29 lazy Montgomery form of fieldx.cuh.  The transform is linear, so
+// the saturated Montgomery words of an input are only regrouped into 29-bit limbs (the value read
+// that way is the element times 2^-5, and the outputs carry the same factor back); only the
+// twiddle tables are true x-form values.  Elements in LDS and in the intermediate image stay
+// below 2p.
+typedef xe_t<FrX> frx;
+struct alignas(16) frx_slot {
+    uint32_t w[12];  // 9 limbs + 3 pad words
+};
+__device__ __forceinline__ frx ld_tw(const frx_slot* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    frx r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
+    return r;
+}
+
 struct NttPassArgs {
     const fr_t* in;
     fr_t* out;
-    const fr_t* pre;     // [2^R] multiplies input digit d (nullable)
-    const fr_t* post;    // [2^R] multiplies output digit k (nullable)
-    const fr_t* sub_tw;  // w_{2^11}^j
-    const fr_t* tw_lo;   // w_N^j, j < 2^logL
-    const fr_t* tw_hi;   // w_N^(j << logL)
+    const frx_slot* pre;     // [2^R] multiplies input digit d (nullable)
+    const frx_slot* post;    // [2^R] multiplies output digit k (nullable)
+    const frx_slot* sub_tw;  // w_{2^11}^j
+    const frx_slot* tw_lo;   // w_N^j, j < 2^logL
+    const frx_slot* tw_hi;   // w_N^(j << logL)
     uint32_t log_n, R, log_s, log_c, log_h, log_l;
     uint32_t n_prev;              // number of earlier sweeps
     uint32_t r_prev[NTT_MAX_PASSES];
@@ -54,6 +73,25 @@ __device__ __forceinline__ uint32_t digits_rev(uint32_t hi, uint32_t log_h, uint
     return K;
 }
 
+// an LDS tile: 9 limbs per element in three planes (16 + 16 + 4 bytes)
+struct LdsTile {
+    uint4* a;
+    uint4* b;
+    uint32_t* c;
+    __device__ __forceinline__ frx get(uint32_t i) const {
+        const uint4 x = a[i], y = b[i];
+        frx r;
+        r.l[0] = x.x; r.l[1] = x.y; r.l[2] = x.z; r.l[3] = x.w; r.l[4] = y.x; r.l[5] = y.y; r.l[6] = y.z; r.l[7] = y.w;
+        r.l[8] = c[i];
+        return r;
+    }
+    __device__ __forceinline__ void put(uint32_t i, const frx& v) const {
+        a[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        b[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+        c[i] = v.l[8];
+    }
+};
+
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const uint32_t R = p.R, log_c = p.log_c;
@@ -63,8 +101,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     // row; other sweeps: image [d][c].
     const bool rowmajor = p.is_last != 0;
     const uint32_t plane = rowmajor ? (C * (Np + 1)) : T;
-    uint4* lds_lo = lds;
-    uint4* lds_hi = lds + plane;
+    LdsTile tile_mem;
+    tile_mem.a = lds;
+    tile_mem.b = lds + plane;
+    tile_mem.c = reinterpret_cast<uint32_t*>(lds + 2 * plane);
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const fr_t* in = p.in + (size_t)blockIdx.y * p.batch_stride;
@@ -85,7 +125,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     }
     auto lds_index = [&](uint32_t d, uint32_t c) -> uint32_t { return rowmajor ? (c * (Np + 1) + d) : ((d << log_c) + c); };
 
-    // ---- load ----
+    // ---- load: canonical input on the first sweep, below 2p afterwards ----
     for (uint32_t e = tid; e < T; e += NTT_THREADS) {
         uint32_t c, d;
         size_t addr;
@@ -99,11 +139,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             d = e >> log_c;
             addr = ((size_t)hi << (R + p.log_s)) + ((size_t)d << p.log_s) + lo_base + c;
         }
-        fr_t x = ld(in + addr);
-        if (p.pre) x = fr_mul(x, ld(p.pre + d));
-        const uint32_t li = lds_index(d, c);
-        lds_lo[li] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-        lds_hi[li] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+        frx x = x_repack_in<FrX>(ld(in + addr));
+        if (p.pre) x = x_mul<FrX>(x, ld_tw(p.pre + d));
+        tile_mem.put(lds_index(d, c), x);
     }
     __syncthreads();
 
@@ -122,20 +160,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             const uint32_t j = bq & (m - 1);
             const uint32_t d0 = ((bq >> s) << (s + 1)) + j;
             const uint32_t i0 = lds_index(d0, c), i1 = lds_index(d0 + m, c);
-            fr_t u, v;
-            {
-                uint4 a = lds_lo[i0], b = lds_hi[i0];
-                u.l[0] = a.x; u.l[1] = a.y; u.l[2] = a.z; u.l[3] = a.w; u.l[4] = b.x; u.l[5] = b.y; u.l[6] = b.z; u.l[7] = b.w;
-                a = lds_lo[i1]; b = lds_hi[i1];
-                v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-            }
-            fr_t sum = fr_add(u, v);
-            fr_t dif = fr_sub(u, v);
-            if (s != 0) dif = fr_mul(dif, ld(p.sub_tw + ((size_t)j << (NTT_SUBTW_LOG - 1 - s))));
-            lds_lo[i0] = make_uint4(sum.l[0], sum.l[1], sum.l[2], sum.l[3]);
-            lds_hi[i0] = make_uint4(sum.l[4], sum.l[5], sum.l[6], sum.l[7]);
-            lds_lo[i1] = make_uint4(dif.l[0], dif.l[1], dif.l[2], dif.l[3]);
-            lds_hi[i1] = make_uint4(dif.l[4], dif.l[5], dif.l[6], dif.l[7]);
+            const frx u = tile_mem.get(i0), v = tile_mem.get(i1);
+            const frx sum = x_csub<FrX, 2>(x_add<FrX>(u, v));  // < 2p
+            frx dif = x_sub<FrX, 2>(u, v);                     // < 4p
+            if (s != 0) dif = x_mul<FrX>(dif, ld_tw(p.sub_tw + ((size_t)j << (NTT_SUBTW_LOG - 1 - s))));
+            else dif = x_csub<FrX, 2>(dif);
+            tile_mem.put(i0, sum);
+            tile_mem.put(i1, dif);
         }
         __syncthreads();
     }
@@ -145,18 +176,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     for (uint32_t e = tid; e < T; e += NTT_THREADS) {
         const uint32_t c = e & (C - 1);
         const uint32_t k = e >> log_c;
-        const uint32_t li = lds_index(brev(k, R), c);
-        fr_t x;
-        {
-            uint4 a = lds_lo[li], b = lds_hi[li];
-            x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
-        }
-        if (p.post) x = fr_mul(x, ld(p.post + k));
+        frx x = tile_mem.get(lds_index(brev(k, R), c));
+        if (p.post) x = x_mul<FrX>(x, ld_tw(p.post + k));
         size_t addr;
         if (p.is_last) {
             const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
             const uint32_t K = digits_rev(hi_c, p.log_h, p.n_prev, p.r_prev);
             addr = (size_t)K + ((size_t)k << p.log_h);
+            x = x_canon2<FrX>(x);   // the transform's output is canonical
         } else {
             // twiddle w_N^(i_next * S_next * K_p),  K_p = K_hi + 2^log_h * k
             const uint32_t lo = lo_base + c;
@@ -164,13 +191,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             const uint64_t Kp = (uint64_t)K_hi + ((uint64_t)k << p.log_h);
             const uint64_t ex = (inext_s * Kp) & (((uint64_t)1 << p.log_n) - 1);
             if (ex) {
-                const fr_t wl = ld(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
-                const fr_t wh = ld(p.tw_hi + (ex >> p.log_l));
-                x = fr_mul(x, fr_mul(wl, wh));
+                const frx wl = ld_tw(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
+                const frx wh = ld_tw(p.tw_hi + (ex >> p.log_l));
+                x = x_mul<FrX>(x, x_mul<FrX>(wl, wh));
             }
             addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
         }
-        st(out + addr, x);
+        st(out + addr, x_repack_out<FrX>(x));
     }
 }
 
@@ -179,8 +206,8 @@ struct NttPlan {
     uint32_t log_n = 0, flags = 0, n_pass = 0;
     uint32_t R[NTT_MAX_PASSES] = {0, 0, 0, 0};
     uint32_t log_l = 0;
-    DevBuf<fr_t> sub_tw, tw_lo, tw_hi;
-    DevBuf<fr_t> pre[NTT_MAX_PASSES], post[NTT_MAX_PASSES];
+    DevBuf<frx_slot> sub_tw, tw_lo, tw_hi;
+    DevBuf<frx_slot> pre[NTT_MAX_PASSES], post[NTT_MAX_PASSES];
     host::fr_h shift;
 };
 
@@ -194,9 +221,22 @@ Ctx::~Ctx() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-static void upload(DevBuf<fr_t>& buf, const std::vector<host::fr_h>& v) {
-    buf.alloc(v.size());
-    if (!v.empty()) HIP_CHECK(hipMemcpy(buf.p, v.data(), v.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+// Montgomery (radix 2^256) host values -> x-form slots: times 2^5, regrouped into 29-bit limbs
+static void upload(DevBuf<frx_slot>& buf, const std::vector<host::fr_h>& v) {
+    const host::fr_h k32 = host::Fr::from_u64(32);
+    std::vector<frx_slot> x(v.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        const host::fr_h t = host::Fr::mul(v[i], k32);
+        memset(&x[i], 0, sizeof(frx_slot));
+        for (int k = 0; k < 9; ++k) {
+            const int bit = k * 29, limb = bit / 64, off = bit % 64;
+            uint64_t w = t.l[limb] >> off;
+            if (off > 64 - 29 && limb + 1 < 4) w |= t.l[limb + 1] << (64 - off);
+            x[i].w[k] = (uint32_t)w & ((1u << 29) - 1u);
+        }
+    }
+    buf.alloc(x.size());
+    if (!x.empty()) HIP_CHECK(hipMemcpy(buf.p, x.data(), x.size() * sizeof(frx_slot), hipMemcpyHostToDevice));
 }
 
 static std::vector<host::fr_h> powers(const host::fr_h& base, size_t count) {
@@ -286,7 +326,7 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));  // two tiles per CU
         attr_set = true;
     }
     fr_t* tmp = nullptr;
@@ -326,7 +366,7 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
         a.log_c = log_c;
         const uint32_t tiles = 1u << (log_n - R - log_c);
         const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
-        const size_t lds_bytes = elems * 32;
+        const size_t lds_bytes = elems * 36;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
         HIP_CHECK(hipGetLastError());
         log_h += R;
