@@ -143,6 +143,37 @@ __device__ __forceinline__ xe_t<X> x_sub(const xe_t<X>& a, const xe_t<X>& b) {
     return x_norm<X>(t);
 }
 
+// ---- carry-free forms: limbs may run past 29 bits (an x_mul accepts a first operand with limbs
+//      below 2^31 when the second is normalised); x_norm_u brings them back ----
+template <class X>
+__device__ __forceinline__ xe_t<X> x_norm_u(const xe_t<X>& a) {  // limbs are unsigned 32-bit quantities
+    xe_t<X> r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < X::L - 1; ++k) {
+        const uint32_t t = a.l[k] + carry;   // a.l[k] <= 2^32 - 8
+        r.l[k] = t & XMASK;
+        carry = t >> 29;
+    }
+    r.l[X::L - 1] = a.l[X::L - 1] + carry;
+    return r;
+}
+template <class X>
+__device__ __forceinline__ xe_t<X> x_add_lazy(const xe_t<X>& a, const xe_t<X>& b) {
+    xe_t<X> t;
+#pragma unroll
+    for (int k = 0; k < X::L; ++k) t.l[k] = a.l[k] + b.l[k];
+    return t;
+}
+// a - b + M p without carries, M in {3, 5}: b normalised and below (M - 1) p
+template <class X, int M>
+__device__ __forceinline__ xe_t<X> x_sub_lazy(const xe_t<X>& a, const xe_t<X>& b) {
+    xe_t<X> t;
+#pragma unroll
+    for (int k = 0; k < X::L; ++k) t.l[k] = a.l[k] + ((M == 3 ? X::bp3(k) : X::bp5(k)) - b.l[k]);
+    return t;
+}
+
 // a - K if a >= K else a, for K given limb-wise (normalised); a normalised
 template <class X, int WHICH>
 __device__ __forceinline__ xe_t<X> x_csub(const xe_t<X>& a) {

@@ -23,7 +23,7 @@ namespace plonk {
 static constexpr int NTT_MAX_PASSES = 4;
 static constexpr int NTT_TILE_LOG = 11;      // elements per LDS tile = 2^11 (64 KiB of Fr)
 static constexpr int NTT_SUBTW_LOG = 11;     // sub_tw holds w_{2^11}^j, j < 2^10
-static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_THREADS = 512;
 
 // Arithmetic runs in the radix-2^29 lazy Montgomery form of fieldx.cuh.  The transform is linear, so
 // the saturated Montgomery words of an input are only regrouped into 29-bit limbs (the value read
@@ -105,8 +105,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     tile_mem.a = lds;
     tile_mem.b = lds + plane;
     tile_mem.c = reinterpret_cast<uint32_t*>(lds + 2 * plane);
+    // w_{Np}^e, e < Np/2, behind the data planes
+    LdsTile tw_mem;
+    {
+        const uint32_t half = Np >> 1;
+        uint4* base = lds + ((plane * 36 + 15) >> 4);
+        tw_mem.a = base;
+        tw_mem.b = base + half;
+        tw_mem.c = reinterpret_cast<uint32_t*>(base + 2 * half);
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
+    for (uint32_t e = tid; e < (Np >> 1); e += NTT_THREADS) tw_mem.put(e, ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))));
     const fr_t* in = p.in + (size_t)blockIdx.y * p.batch_stride;
     fr_t* out = p.out + (size_t)blockIdx.y * p.batch_stride;
 
@@ -145,28 +155,74 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     }
     __syncthreads();
 
-    // ---- log2(Np) decimation-in-frequency stages; result lands bit-reversed in d ----
-    for (uint32_t s = R; s-- > 0;) {
-        const uint32_t m = 1u << s;
+    // ---- log2(Np) decimation-in-time stages on natural-order input (the twiddle of a butterfly
+    //      depends on its block, in bit-reversed order); the result lands bit-reversed in d.
+    //      Two stages at a time in registers; the stage s = R-1 has twiddle 1 throughout.
+    //      Only the multiplied operand of a butterfly is reduced (below 2p): an element grows by at
+    //      most 3p per stage, at most 35p over the 11 stages a sweep can have. ----
+    uint32_t s = R;
+    if (R & 1u) {
+        const uint32_t m = Np >> 1;
         for (uint32_t q = tid; q < (T >> 1); q += NTT_THREADS) {
-            uint32_t c, bq;
+            uint32_t c, j;
             if (rowmajor) {
-                bq = q & ((Np >> 1) - 1);
+                j = q & (m - 1);
                 c = q >> (R - 1);
             } else {
                 c = q & (C - 1);
-                bq = q >> log_c;
+                j = q >> log_c;
             }
-            const uint32_t j = bq & (m - 1);
-            const uint32_t d0 = ((bq >> s) << (s + 1)) + j;
-            const uint32_t i0 = lds_index(d0, c), i1 = lds_index(d0 + m, c);
+            const uint32_t i0 = lds_index(j, c), i1 = lds_index(j + m, c);
             const frx u = tile_mem.get(i0), v = tile_mem.get(i1);
-            const frx sum = x_csub<FrX, 2>(x_add<FrX>(u, v));  // < 2p
-            frx dif = x_sub<FrX, 2>(u, v);                     // < 4p
-            if (s != 0) dif = x_mul<FrX>(dif, ld_tw(p.sub_tw + ((size_t)j << (NTT_SUBTW_LOG - 1 - s))));
-            else dif = x_csub<FrX, 2>(dif);
-            tile_mem.put(i0, sum);
-            tile_mem.put(i1, dif);
+            tile_mem.put(i0, x_norm_u<FrX>(x_add_lazy<FrX>(u, v)));      // < 4p
+            tile_mem.put(i1, x_norm_u<FrX>(x_sub_lazy<FrX, 3>(u, v)));   // < 5p
+        }
+        __syncthreads();
+        s = R - 1;
+    }
+    for (; s >= 2; s -= 2) {
+        const uint32_t h = 1u << (s - 2);
+        const bool first = s == R;
+        for (uint32_t q = tid; q < (T >> 2); q += NTT_THREADS) {
+            uint32_t c, g;
+            if (rowmajor) {
+                g = q & ((Np >> 2) - 1);
+                c = q >> (R - 2);
+            } else {
+                c = q & (C - 1);
+                g = q >> log_c;
+            }
+            const uint32_t j = g & (h - 1), blk = g >> (s - 2);
+            const uint32_t d0 = (blk << s) + j;
+            const uint32_t i0 = lds_index(d0, c), i1 = lds_index(d0 + h, c), i2 = lds_index(d0 + 2 * h, c),
+                           i3 = lds_index(d0 + 3 * h, c);
+            const frx x0 = tile_mem.get(i0), x1 = tile_mem.get(i1), x2 = tile_mem.get(i2), x3 = tile_mem.get(i3);
+            frx z0, z1, z2, z3;
+            if (first) {
+                // stages R-1 and R-2 of block 0: the only twiddle that is not 1 is w_4
+                const frx y0 = x_add_lazy<FrX>(x0, x2), y2 = x_sub_lazy<FrX, 3>(x0, x2);
+                const frx y1 = x_norm_u<FrX>(x_add_lazy<FrX>(x1, x3)), y3 = x_sub_lazy<FrX, 3>(x1, x3);
+                const frx t3 = x_mul<FrX>(y3, tw_mem.get(Np >> 2));
+                z0 = x_add_lazy<FrX>(y0, y1);        // < 8p
+                z1 = x_sub_lazy<FrX, 5>(y0, y1);     // < 9p
+                z2 = x_add_lazy<FrX>(y2, t3);
+                z3 = x_sub_lazy<FrX, 3>(y2, t3);
+            } else {
+                const uint32_t ea = brev(blk, R - s) << (s - 2);
+                const frx ts = tw_mem.get(2 * ea);
+                const frx t2 = x_mul<FrX>(x2, ts), t3 = x_mul<FrX>(x3, ts);
+                const frx y0 = x_add_lazy<FrX>(x0, t2), y2 = x_sub_lazy<FrX, 3>(x0, t2);
+                const frx y1 = x_add_lazy<FrX>(x1, t3), y3 = x_sub_lazy<FrX, 3>(x1, t3);
+                const frx u1 = x_mul<FrX>(y1, tw_mem.get(ea)), u3 = x_mul<FrX>(y3, tw_mem.get(ea + (Np >> 2)));
+                z0 = x_add_lazy<FrX>(y0, u1);
+                z1 = x_sub_lazy<FrX, 3>(y0, u1);
+                z2 = x_add_lazy<FrX>(y2, u3);
+                z3 = x_sub_lazy<FrX, 3>(y2, u3);     // < input + 6p
+            }
+            tile_mem.put(i0, x_norm_u<FrX>(z0));
+            tile_mem.put(i1, x_norm_u<FrX>(z1));
+            tile_mem.put(i2, x_norm_u<FrX>(z2));
+            tile_mem.put(i3, x_norm_u<FrX>(z3));
         }
         __syncthreads();
     }
@@ -183,6 +239,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
             const uint32_t K = digits_rev(hi_c, p.log_h, p.n_prev, p.r_prev);
             addr = (size_t)K + ((size_t)k << p.log_h);
+            if (!p.post) x = x_mul<FrX>(x, x_one<FrX>());   // below 2p, same residue
             x = x_canon2<FrX>(x);   // the transform's output is canonical
         } else {
             // twiddle w_N^(i_next * S_next * K_p),  K_p = K_hi + 2^log_h * k
@@ -190,11 +247,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             const uint64_t inext_s = (uint64_t)(lo >> p.log_s_next) << p.log_s_next;
             const uint64_t Kp = (uint64_t)K_hi + ((uint64_t)k << p.log_h);
             const uint64_t ex = (inext_s * Kp) & (((uint64_t)1 << p.log_n) - 1);
-            if (ex) {
-                const frx wl = ld_tw(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
-                const frx wh = ld_tw(p.tw_hi + (ex >> p.log_l));
-                x = x_mul<FrX>(x, x_mul<FrX>(wl, wh));
-            }
+            // (also what brings the element back below 2p, so it is not skipped for ex == 0)
+            const frx wl = ld_tw(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
+            const frx wh = ld_tw(p.tw_hi + (ex >> p.log_l));
+            x = x_mul<FrX>(x, x_mul<FrX>(wl, wh));
             addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
         }
         st(out + addr, x_repack_out<FrX>(x));
@@ -326,7 +382,7 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));  // two tiles per CU
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         attr_set = true;
     }
     fr_t* tmp = nullptr;
@@ -366,7 +422,7 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
         a.log_c = log_c;
         const uint32_t tiles = 1u << (log_n - R - log_c);
         const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
-        const size_t lds_bytes = elems * 36;
+        const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + ((size_t)1 << R) / 2 * 36 + 16;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
         HIP_CHECK(hipGetLastError());
         log_h += R;
