@@ -51,44 +51,64 @@ struct DigitIter {
     }
 };
 
-// ---- 1. histogram of (window, |digit|) ----
-// `shared`: all windows feed ONE bucket set (the points of window w are then the precomputed
-// 2^(c w) P_i of the SRS table), otherwise window w has its own bucket set w.
-__global__ __launch_bounds__(256) void msm_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                        uint32_t nb, uint32_t shared, uint32_t* __restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    DigitIter it(ld(scalars + i), c);
-    for (uint32_t w = 0; w < W; ++w) {
-        const int32_t d = it.next();
-        if (d != 0) atomicAdd(&counts[(size_t)(shared ? 0u : w) * nb + (uint32_t)(d < 0 ? -d : d)], 1u);
-    }
+// ---- 1-3. group the (point, sign) entries by bucket.  A bucket id is gid = set * 2^(c-1) + |digit| - 1,
+//          where `shared` mode has a single set (all windows feed ONE bucket set: the points of
+//          window w are then the precomputed 2^(c w) P_i of the SRS table) and otherwise window w
+//          is set w.  Two levels, both counting in LDS and never with global atomics:
+//            coarse: slabs of SORT_SLAB scalars; workgroup g counts its entries per coarse bin
+//                    (gid >> low_bits) into wg_counts[bin][g]; a scan of that matrix gives every
+//                    (bin, g) its own output run; the entries go there as (payload, gid low bits).
+//            fine:   one workgroup per coarse bin sorts its run by the low bits in LDS and emits
+//                    the per-bucket counts / offsets and the final entry list. ----
+constexpr uint32_t SORT_SLAB = 1024;       // scalars per coarse workgroup (256 lanes x 4)
+constexpr uint32_t SORT_MAX_COARSE = 2048; // coarse bins (LDS counters)
+constexpr uint32_t SORT_MAX_LOW = 11;      // low bits sorted by the fine pass (2048 LDS counters)
+
+__device__ __forceinline__ uint32_t digit_gid(int32_t d, uint32_t w, uint32_t shared, uint32_t nbk) {
+    return (shared ? 0u : w) * nbk + (uint32_t)(d < 0 ? -d : d) - 1u;
 }
 
-// ---- 2. exclusive scan of the counts of every bucket set, in tiles of SCAN_TILE entries:
-//         tile sums -> scan of the tile sums (one workgroup per set) -> scan inside each tile ----
+__global__ __launch_bounds__(256) void msm_coarse_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
+                                                               uint32_t W, uint32_t nbk, uint32_t shared, uint32_t low_bits,
+                                                               uint32_t n_coarse, uint32_t* __restrict__ wg_counts) {
+    __shared__ uint32_t h[SORT_MAX_COARSE];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) h[k] = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r < SORT_SLAB / 256; ++r) {
+        const uint32_t i = blockIdx.x * SORT_SLAB + r * 256 + threadIdx.x;
+        if (i >= n) break;
+        DigitIter it(ld(scalars + i), c);
+        for (uint32_t w = 0; w < W; ++w) {
+            const int32_t d = it.next();
+            if (d != 0) atomicAdd(&h[digit_gid(d, w, shared, nbk) >> low_bits], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) wg_counts[(size_t)k * gridDim.x + blockIdx.x] = h[k];
+}
+
+// ---- exclusive scan of a vector in tiles of SCAN_TILE entries:
+//      tile sums -> scan of the tile sums (one workgroup) -> scan inside each tile ----
 constexpr uint32_t SCAN_TILE = 4096;   // 256 lanes x 16 consecutive entries
 
 __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
-                                                              uint32_t tiles, uint32_t* __restrict__ tile_sums) {
+                                                              uint32_t* __restrict__ tile_sums) {
     __shared__ uint32_t part[256];
-    const uint32_t set = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
-    const uint32_t* src = counts + (size_t)set * nb;
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     uint32_t sum = 0;
-    for (uint32_t k = tile * SCAN_TILE + tid; k < min(nb, (tile + 1) * SCAN_TILE); k += 256) sum += src[k];
+    for (uint32_t k = tile * SCAN_TILE + tid; k < min(nb, (tile + 1) * SCAN_TILE); k += 256) sum += counts[k];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (tid < s) part[tid] += part[tid + s];
         __syncthreads();
     }
-    if (tid == 0) tile_sums[blockIdx.x] = part[0];
+    if (tid == 0) tile_sums[tile] = part[0];
 }
 
-__global__ __launch_bounds__(1024) void msm_scan_sums_kernel(uint32_t* __restrict__ tile_sums, uint32_t tiles) {
+__global__ __launch_bounds__(1024) void msm_scan_sums_kernel(uint32_t* __restrict__ v, uint32_t tiles) {
     __shared__ uint32_t part[1024];
-    const uint32_t set = blockIdx.x, tid = threadIdx.x;
-    uint32_t* v = tile_sums + (size_t)set * tiles;
+    const uint32_t tid = threadIdx.x;
     const uint32_t per = (tiles + 1023) / 1024;
     const uint32_t lo = min(tiles, tid * per), hi = min(tiles, lo + per);
     uint32_t sum = 0;
@@ -109,17 +129,16 @@ __global__ __launch_bounds__(1024) void msm_scan_sums_kernel(uint32_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t tiles,
+__global__ __launch_bounds__(256) void msm_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
                                                         const uint32_t* __restrict__ tile_sums,
-                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+                                                        uint32_t* __restrict__ offsets) {
     __shared__ uint32_t part[256];
-    const uint32_t set = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
-    const size_t base = (size_t)set * nb;
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t lo = min(nb, tile * SCAN_TILE + tid * 16), hi = min(nb, lo + 16);
     uint32_t v[16], sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
-        v[k] = lo + k < hi ? counts[base + lo + k] : 0u;
+        v[k] = lo + k < hi ? counts[lo + k] : 0u;
         sum += v[k];
     }
     part[tid] = sum;
@@ -130,32 +149,83 @@ __global__ __launch_bounds__(256) void msm_scan_kernel(const uint32_t* __restric
         part[tid] += t;
         __syncthreads();
     }
-    uint32_t run = tile_sums[blockIdx.x] + part[tid] - sum;
+    uint32_t run = tile_sums[tile] + part[tid] - sum;
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
-        if (lo + k < hi) {
-            offsets[base + lo + k] = run;
-            cursor[base + lo + k] = run;
-        }
+        if (lo + k < hi) offsets[lo + k] = run;
         run += v[k];
     }
 }
 
-// ---- 3. scatter: digits are recomputed rather than stored ----
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                           uint32_t nb, uint32_t shared, uint32_t level_stride,
-                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    DigitIter it(ld(scalars + i), c);
-    for (uint32_t w = 0; w < W; ++w) {
-        const int32_t d = it.next();
-        if (d == 0) continue;
-        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        const uint32_t set = shared ? 0u : w;
-        const uint32_t pos = atomicAdd(&cursor[(size_t)set * nb + mag], 1u);
-        const uint32_t point = shared ? w * level_stride + i : i;   // row w of the SRS table
-        sorted[(size_t)set * n + pos] = point | (d < 0 ? SIGN_BIT : 0u);
+// coarse scatter: wg_offsets is the exclusive scan of wg_counts (bin-major)
+__global__ __launch_bounds__(256) void msm_coarse_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
+                                                                  uint32_t W, uint32_t nbk, uint32_t shared,
+                                                                  uint32_t level_stride, uint32_t low_bits, uint32_t n_coarse,
+                                                                  const uint32_t* __restrict__ wg_offsets,
+                                                                  uint2* __restrict__ coarse) {
+    __shared__ uint32_t cur[SORT_MAX_COARSE];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) cur[k] = wg_offsets[(size_t)k * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const uint32_t low_mask = (1u << low_bits) - 1u;
+    for (uint32_t r = 0; r < SORT_SLAB / 256; ++r) {
+        const uint32_t i = blockIdx.x * SORT_SLAB + r * 256 + threadIdx.x;
+        if (i >= n) break;
+        DigitIter it(ld(scalars + i), c);
+        for (uint32_t w = 0; w < W; ++w) {
+            const int32_t d = it.next();
+            if (d == 0) continue;
+            const uint32_t gid = digit_gid(d, w, shared, nbk);
+            const uint32_t pos = atomicAdd(&cur[gid >> low_bits], 1u);
+            const uint32_t point = shared ? w * level_stride + i : i;   // row w of the SRS table
+            coarse[pos] = make_uint2(point | (d < 0 ? SIGN_BIT : 0u), gid & low_mask);
+        }
+    }
+}
+
+// fine sort of coarse bin blockIdx.x: its run is [wg_offsets[bin * num_wg], wg_offsets[(bin + 1) * num_wg])
+// (wg_offsets has one entry past the matrix, the total).
+__global__ __launch_bounds__(1024) void msm_fine_sort_kernel(const uint2* __restrict__ coarse,
+                                                              const uint32_t* __restrict__ wg_offsets, uint32_t num_wg,
+                                                              uint32_t low_bits, uint32_t total_buckets,
+                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t h[1u << SORT_MAX_LOW];
+    __shared__ uint32_t part[1024];
+    const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo = wg_offsets[(size_t)bin * num_wg], hi = wg_offsets[(size_t)(bin + 1) * num_wg];
+    const uint32_t nlow = 1u << low_bits;
+    for (uint32_t k = tid; k < nlow; k += 1024) h[k] = 0;
+    __syncthreads();
+    for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&h[coarse[e].y], 1u);
+    __syncthreads();
+    // exclusive scan of h (at most 2 entries per lane)
+    const uint32_t per = (nlow + 1023) / 1024;
+    const uint32_t k0 = min(nlow, tid * per), k1 = min(nlow, k0 + per);
+    uint32_t sum = 0;
+    for (uint32_t k = k0; k < k1; ++k) sum += h[k];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = lo + part[tid] - sum;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t cnt = h[k];
+        const uint32_t gid = (bin << low_bits) + k;
+        if (gid < total_buckets) {
+            counts[gid] = cnt;
+            offsets[gid] = run;
+        }
+        h[k] = run;   // becomes the cursor
+        run += cnt;
+    }
+    __syncthreads();
+    for (uint32_t e = lo + tid; e < hi; e += 1024) {
+        const uint2 v = coarse[e];
+        sorted[atomicAdd(&h[v.y], 1u)] = v.x;
     }
 }
 
@@ -163,15 +233,14 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const fr_t* __restrict
 __device__ __forceinline__ uint32_t order_bin(uint32_t cnt) {  // bin 0 = big buckets, then sizes BIG..0
     return cnt > BIG_BUCKET ? 0u : 1u + (BIG_BUCKET - cnt);
 }
-__global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
+__global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts,
                                                               uint32_t total_buckets, uint32_t* __restrict__ bins) {
     __shared__ uint32_t h[ORDER_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < total_buckets) {
-        const uint32_t nbk = nb - 1;
-        atomicAdd(&h[order_bin(counts[(size_t)(gid / nbk) * nb + gid % nbk + 1])], 1u);
+        atomicAdd(&h[order_bin(counts[gid])], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
@@ -191,7 +260,7 @@ __global__ __launch_bounds__(256) void msm_order_scan_kernel(uint32_t* __restric
     bins[tid] = part[tid] - v;  // exclusive start of each bin
     if (tid == 0) *n_big = v;
 }
-__global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t nb,
+__global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts,
                                                                  uint32_t total_buckets, uint32_t* __restrict__ bins,
                                                                  uint32_t* __restrict__ order) {
     __shared__ uint32_t h[ORDER_BINS];
@@ -201,8 +270,7 @@ __global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* 
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bin = 0, rank = 0;
     if (gid < total_buckets) {
-        const uint32_t nbk = nb - 1;
-        bin = order_bin(counts[(size_t)(gid / nbk) * nb + gid % nbk + 1]);
+        bin = order_bin(counts[gid]);
         rank = atomicAdd(&h[bin], 1u);
     }
     __syncthreads();
@@ -221,16 +289,14 @@ __device__ __forceinline__ AffX load_signed_point(const g1x_affine_t* points, ui
 __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __restrict__ points,
                                                           const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
+                                                          const uint32_t* __restrict__ counts,
                                                           uint32_t total_buckets, const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ n_big, g1x_xyzz_t* __restrict__ buckets) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x + *n_big;
     if (slot >= total_buckets) return;
     const uint32_t gid = order[slot];
-    const uint32_t nbk = nb - 1;
-    const uint32_t w = gid / nbk, b = gid % nbk + 1;
-    const uint32_t cnt = counts[(size_t)w * nb + b];
-    const uint32_t* src = sorted + (size_t)w * n + offsets[(size_t)w * nb + b];
+    const uint32_t cnt = counts[gid];
+    const uint32_t* src = sorted + offsets[gid];
     PtX acc = ptx_identity();
     for (uint32_t k = 0; k < cnt; ++k) {
         const AffX p = load_signed_point(points, src[k]);
@@ -243,7 +309,7 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t* __restrict__ points,
                                                               const uint32_t* __restrict__ sorted,
                                                               const uint32_t* __restrict__ offsets,
-                                                              const uint32_t* __restrict__ counts, uint32_t n, uint32_t nb,
+                                                              const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ order,
                                                               const uint32_t* __restrict__ n_big,
                                                               g1x_xyzz_t* __restrict__ buckets) {
@@ -252,10 +318,8 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
     const uint32_t nbig = *n_big;
     for (uint32_t item = blockIdx.x; item < nbig; item += gridDim.x) {
         const uint32_t gid = order[item];
-        const uint32_t nbk = nb - 1;
-        const uint32_t w = gid / nbk, b = gid % nbk + 1;
-        const uint32_t cnt = counts[(size_t)w * nb + b];
-        const uint32_t* src = sorted + (size_t)w * n + offsets[(size_t)w * nb + b];
+        const uint32_t cnt = counts[gid];
+        const uint32_t* src = sorted + offsets[gid];
         PtX acc = ptx_identity();
         for (uint32_t k = tid; k < cnt; k += 256) {
             const AffX p = load_signed_point(points, src[k]);
@@ -388,7 +452,8 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
 // tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
     hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;
-    DevBuf<uint32_t> sorted, counts, offsets, cursor, tile_sums, order, bins;
+    DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, order, bins;
+    DevBuf<uint2> coarse;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
@@ -445,7 +510,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     const uint32_t c = shared ? pts.table_c : msm_window_bits(n);
     const uint32_t W = (256 + c - 1) / c;
     const uint32_t S = shared ? 1u : W;   // bucket sets
-    const uint32_t nbk = 1u << (c - 1), nb = nbk + 1;
+    const uint32_t nbk = 1u << (c - 1);
     const uint32_t total_buckets = S * nbk;
     const uint32_t chunks = nbk >> CHUNK_LOG, total_chunks = S * chunks;
     uint32_t log_chunks = 0;
@@ -454,12 +519,22 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     const uint32_t parts = std::max(1u, chunks / 2048);
     PLONK_REQUIRE(parts <= 64, "msm: window too wide for the reduction");
     s.c = c; s.W = S; s.nq = nq; s.log_chunks = log_chunks;
+    // sort geometry: low_bits of the bucket id are sorted per coarse bin, the rest select the bin
+    uint32_t kbits = 0;
+    while ((1u << kbits) < total_buckets) ++kbits;
+    const uint32_t low_bits = std::min(SORT_MAX_LOW, std::max(2u, kbits > 9 ? kbits - 9 : 0u));
+    const uint32_t n_coarse = (total_buckets + (1u << low_bits) - 1) >> low_bits;
+    PLONK_REQUIRE(n_coarse <= SORT_MAX_COARSE, "msm: too many buckets for the sort");
+    const uint32_t num_wg = (uint32_t)((n + SORT_SLAB - 1) / SORT_SLAB);
+    const uint32_t matrix = n_coarse * num_wg + 1;   // + the total
+    const uint32_t tiles = (matrix + SCAN_TILE - 1) / SCAN_TILE;
     s.sorted.ensure((size_t)W * n);
-    s.counts.ensure((size_t)S * nb);
-    s.offsets.ensure((size_t)S * nb);
-    s.cursor.ensure((size_t)S * nb);
-    const uint32_t tiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
-    s.tile_sums.ensure((size_t)S * tiles);
+    s.coarse.ensure((size_t)W * n);
+    s.wg_counts.ensure(matrix);
+    s.wg_offsets.ensure(matrix);
+    s.tile_sums.ensure(tiles);
+    s.counts.ensure(total_buckets);
+    s.offsets.ensure(total_buckets);
     s.order.ensure(total_buckets);
     s.bins.ensure(ORDER_BINS + 4);
     s.buckets.ensure(total_buckets);
@@ -473,32 +548,34 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
         HIP_CHECK(hipHostMalloc((void**)&s.host_sums, (size_t)S * nq * sizeof(g1_xyzz_t), hipHostMallocDefault));
         s.host_cap = (size_t)S * nq;
     }
-    const uint32_t nblk = (uint32_t)((n + 255) / 256), bblk = (total_buckets + 255) / 256;
+    const uint32_t bblk = (total_buckets + 255) / 256;
     uint32_t* n_big = s.bins.p + ORDER_BINS;
     hipStream_t st;
     if (!tail_phase) {
     // ---- sort phase (the caller has ordered the sort stream behind the scalars) ----
     st = ws->sort_stream;
-    HIP_CHECK(hipMemsetAsync(s.counts.p, 0, (size_t)S * nb * sizeof(uint32_t), st));
+    HIP_CHECK(hipMemsetAsync(s.wg_counts.p + (matrix - 1), 0, sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, shared, s.counts.p);
-    hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(S * tiles), dim3(256), 0, st, s.counts.p, nb, tiles, s.tile_sums.p);
-    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(S), dim3(1024), 0, st, s.tile_sums.p, tiles);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(S * tiles), dim3(256), 0, st, s.counts.p, nb, tiles, s.tile_sums.p, s.offsets.p,
-                       s.cursor.p);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(nblk), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nb, shared,
-                       (uint32_t)pts.level_stride, s.cursor.p, s.sorted.p);
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p);
+    hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
+                       n_coarse, s.wg_counts.p);
+    hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p);
+    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(1024), 0, st, s.tile_sums.p, tiles);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p, s.wg_offsets.p);
+    hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
+                       (uint32_t)pts.level_stride, low_bits, n_coarse, s.wg_offsets.p, s.coarse.p);
+    hipLaunchKernelGGL(msm_fine_sort_kernel, dim3(n_coarse), dim3(1024), 0, st, s.coarse.p, s.wg_offsets.p, num_wg, low_bits,
+                       total_buckets, s.counts.p, s.offsets.p, s.sorted.p);
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, nb, total_buckets, s.bins.p, s.order.p);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p, s.order.p);
     HIP_CHECK(hipEventRecord(s.sorted_ev, st));
     // ---- bucket phase ----
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
     hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                       (uint32_t)n, nb, s.order.p, n_big, s.buckets.p);
+                       s.order.p, n_big, s.buckets.p);
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                       (uint32_t)n, nb, total_buckets, s.order.p, n_big, s.buckets.p);
+                       total_buckets, s.order.p, n_big, s.buckets.p);
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
     return;
     }

@@ -21,9 +21,9 @@
 namespace plonk {
 
 static constexpr int NTT_MAX_PASSES = 4;
-static constexpr int NTT_TILE_LOG = 11;      // elements per LDS tile = 2^11 (64 KiB of Fr)
+static constexpr int NTT_TILE_LOG = 10;      // elements per LDS tile (36 KiB of 9-limb elements)
 static constexpr int NTT_SUBTW_LOG = 11;     // sub_tw holds w_{2^11}^j, j < 2^10
-static constexpr int NTT_THREADS = 512;
+static constexpr int NTT_THREADS = 256;
 
 // Arithmetic runs in the radix-2^29 lazy Montgomery form of fieldx.cuh.  The transform is linear, so
 // the saturated Montgomery words of an input are only regrouped into 29-bit limbs (the value read
