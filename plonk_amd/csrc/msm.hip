@@ -182,48 +182,90 @@ __global__ __launch_bounds__(256) void msm_coarse_scatter_kernel(const fr_t* __r
     }
 }
 
-// fine sort of coarse bin blockIdx.x: its run is [wg_offsets[bin * num_wg], wg_offsets[(bin + 1) * num_wg])
-// (wg_offsets has one entry past the matrix, the total).
-__global__ __launch_bounds__(1024) void msm_fine_sort_kernel(const uint2* __restrict__ coarse,
+// fine sort of coarse bin blockIdx.x, whose run is [wg_offsets[bin * num_wg], wg_offsets[(bin + 1) * num_wg])
+// (wg_offsets has one entry past the matrix, the total).  The run is cut into at most FINE_MAX_PARTS
+// parts of about FINE_PART entries, one workgroup (blockIdx.y) each, so that a bin swollen by skewed
+// scalars (many equal or small values) still spreads over the chip: the first kernel counts every
+// part by low bits, the second turns the counts into cursors and moves the entries.
+constexpr uint32_t FINE_PART = 8192;
+constexpr uint32_t FINE_MAX_PARTS = 16;
+
+struct FinePart {
+    uint32_t lo, hi, parts, sub_lo, sub_hi;
+};
+__device__ __forceinline__ FinePart fine_part(const uint32_t* wg_offsets, uint32_t num_wg, uint32_t bin, uint32_t part) {
+    FinePart f;
+    f.lo = wg_offsets[(size_t)bin * num_wg];
+    f.hi = wg_offsets[(size_t)(bin + 1) * num_wg];
+    const uint32_t size = f.hi - f.lo;
+    f.parts = min(FINE_MAX_PARTS, max(1u, (size + FINE_PART - 1) / FINE_PART));
+    const uint32_t len = (size + f.parts - 1) / f.parts;
+    f.sub_lo = min(f.hi, f.lo + part * len);
+    f.sub_hi = min(f.hi, f.sub_lo + len);
+    return f;
+}
+
+__global__ __launch_bounds__(1024) void msm_fine_hist_kernel(const uint2* __restrict__ coarse,
                                                               const uint32_t* __restrict__ wg_offsets, uint32_t num_wg,
-                                                              uint32_t low_bits, uint32_t total_buckets,
-                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                              uint32_t* __restrict__ sorted) {
+                                                              uint32_t low_bits, uint32_t* __restrict__ part_hist) {
     __shared__ uint32_t h[1u << SORT_MAX_LOW];
-    __shared__ uint32_t part[1024];
-    const uint32_t bin = blockIdx.x, tid = threadIdx.x;
-    const uint32_t lo = wg_offsets[(size_t)bin * num_wg], hi = wg_offsets[(size_t)(bin + 1) * num_wg];
+    const uint32_t bin = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const FinePart f = fine_part(wg_offsets, num_wg, bin, part);
+    if (part >= f.parts) return;
     const uint32_t nlow = 1u << low_bits;
     for (uint32_t k = tid; k < nlow; k += 1024) h[k] = 0;
     __syncthreads();
-    for (uint32_t e = lo + tid; e < hi; e += 1024) atomicAdd(&h[coarse[e].y], 1u);
+    for (uint32_t e = f.sub_lo + tid; e < f.sub_hi; e += 1024) atomicAdd(&h[coarse[e].y], 1u);
     __syncthreads();
-    // exclusive scan of h (at most 2 entries per lane)
-    const uint32_t per = (nlow + 1023) / 1024;
+    uint32_t* dst = part_hist + (((size_t)bin * FINE_MAX_PARTS + part) << low_bits);
+    for (uint32_t k = tid; k < nlow; k += 1024) dst[k] = h[k];
+}
+
+__global__ __launch_bounds__(1024) void msm_fine_scatter_kernel(const uint2* __restrict__ coarse,
+                                                                 const uint32_t* __restrict__ wg_offsets, uint32_t num_wg,
+                                                                 uint32_t low_bits, uint32_t total_buckets,
+                                                                 const uint32_t* __restrict__ part_hist,
+                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                                 uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t h[1u << SORT_MAX_LOW];
+    __shared__ uint32_t part_sum[1024];
+    const uint32_t bin = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const FinePart f = fine_part(wg_offsets, num_wg, bin, part);
+    if (part >= f.parts) return;
+    const uint32_t nlow = 1u << low_bits;
+    // per low value: entries of the whole bin (tot) and of the parts before this one (pre)
+    const uint32_t per = (nlow + 1023) / 1024;   // 1 or 2
     const uint32_t k0 = min(nlow, tid * per), k1 = min(nlow, k0 + per);
-    uint32_t sum = 0;
-    for (uint32_t k = k0; k < k1; ++k) sum += h[k];
-    part[tid] = sum;
+    uint32_t tot[2] = {0, 0}, pre[2] = {0, 0}, sum = 0;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t* src = part_hist + (((size_t)bin * FINE_MAX_PARTS) << low_bits) + k;
+        for (uint32_t q = 0; q < f.parts; ++q) {
+            const uint32_t v = src[(size_t)q << low_bits];
+            tot[k - k0] += v;
+            if (q < part) pre[k - k0] += v;
+        }
+        sum += tot[k - k0];
+    }
+    part_sum[tid] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t t = tid >= off ? part[tid - off] : 0;
+        uint32_t t = tid >= off ? part_sum[tid - off] : 0;
         __syncthreads();
-        part[tid] += t;
+        part_sum[tid] += t;
         __syncthreads();
     }
-    uint32_t run = lo + part[tid] - sum;
+    uint32_t run = f.lo + part_sum[tid] - sum;
     for (uint32_t k = k0; k < k1; ++k) {
-        const uint32_t cnt = h[k];
         const uint32_t gid = (bin << low_bits) + k;
-        if (gid < total_buckets) {
-            counts[gid] = cnt;
+        if (part == 0 && gid < total_buckets) {
+            counts[gid] = tot[k - k0];
             offsets[gid] = run;
         }
-        h[k] = run;   // becomes the cursor
-        run += cnt;
+        h[k] = run + pre[k - k0];   // this part's cursor
+        run += tot[k - k0];
     }
     __syncthreads();
-    for (uint32_t e = lo + tid; e < hi; e += 1024) {
+    for (uint32_t e = f.sub_lo + tid; e < f.sub_hi; e += 1024) {
         const uint2 v = coarse[e];
         sorted[atomicAdd(&h[v.y], 1u)] = v.x;
     }
@@ -452,7 +494,7 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
 // tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
     hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;
-    DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, order, bins;
+    DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, part_hist, order, bins;
     DevBuf<uint2> coarse;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
@@ -533,6 +575,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     s.wg_counts.ensure(matrix);
     s.wg_offsets.ensure(matrix);
     s.tile_sums.ensure(tiles);
+    s.part_hist.ensure(((size_t)n_coarse * FINE_MAX_PARTS) << low_bits);
     s.counts.ensure(total_buckets);
     s.offsets.ensure(total_buckets);
     s.order.ensure(total_buckets);
@@ -563,8 +606,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     hipLaunchKernelGGL(msm_scan_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p, s.wg_offsets.p);
     hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
                        (uint32_t)pts.level_stride, low_bits, n_coarse, s.wg_offsets.p, s.coarse.p);
-    hipLaunchKernelGGL(msm_fine_sort_kernel, dim3(n_coarse), dim3(1024), 0, st, s.coarse.p, s.wg_offsets.p, num_wg, low_bits,
-                       total_buckets, s.counts.p, s.offsets.p, s.sorted.p);
+    hipLaunchKernelGGL(msm_fine_hist_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p, s.wg_offsets.p,
+                       num_wg, low_bits, s.part_hist.p);
+    hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p,
+                       s.wg_offsets.p, num_wg, low_bits, total_buckets, s.part_hist.p, s.counts.p, s.offsets.p, s.sorted.p);
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
     hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p, s.order.p);
