@@ -209,6 +209,10 @@ __device__ __forceinline__ xe_t<X> x_canon2(const xe_t<X>& a) {
 }
 template <class X>
 __device__ __forceinline__ bool x_is_zero16(const xe_t<X>& a) {
+    // a normalised value below 16p is 0 mod p only if it is k p with k < 16, and then its low limb
+    // times p^-1 mod 2^29 is k: all but 2^-25 of the nonzero values fail this one-multiply test
+    const uint32_t k = (0u - a.l[0] * X::INV) & XMASK;
+    if (k >= 16u) return false;
     return x_limbs_zero<X>(x_canon16<X>(a));
 }
 

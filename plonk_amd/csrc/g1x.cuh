@@ -35,8 +35,25 @@ struct MulInline {
     static __device__ __forceinline__ fqx sqr(const fqx& a) { return x_sqr<FqX>(a); }
 };
 struct MulCall {
-    static __device__ __noinline__ fqx mul(fqx a, fqx b) { return x_mul<FqX>(a, b); }
-    static __device__ __forceinline__ fqx sqr(const fqx& a) { return mul(a, a); }
+    // operands as 14-lane vectors: those travel in registers, a struct argument would go through
+    // scratch memory
+    typedef uint32_t vec __attribute__((ext_vector_type(14)));
+    static __device__ __forceinline__ vec pack(const fqx& a) {
+        vec v;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) v[i] = a.l[i];
+        return v;
+    }
+    static __device__ __forceinline__ fqx unpack(const vec& v) {
+        fqx a;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) a.l[i] = v[i];
+        return a;
+    }
+    static __device__ __noinline__ vec mul_fn(vec a, vec b) { return pack(x_mul<FqX>(unpack(a), unpack(b))); }
+    static __device__ __noinline__ vec sqr_fn(vec a) { return pack(x_sqr<FqX>(unpack(a))); }
+    static __device__ __forceinline__ fqx mul(const fqx& a, const fqx& b) { return unpack(mul_fn(pack(a), pack(b))); }
+    static __device__ __forceinline__ fqx sqr(const fqx& a) { return unpack(sqr_fn(pack(a))); }
 };
 
 __device__ __forceinline__ bool ptx_is_inf(const PtX& p) { return x_limbs_zero<FqX>(p.zz); }

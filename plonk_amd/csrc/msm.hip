@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
         for (uint32_t s = 128; s > 0; s >>= 1) {
             if (tid < s) {
                 const PtX o = ld_ptx(&red[tid + s]);
-                ptx_add<MulCall>(acc, o);
+                ptx_add<MulInline>(acc, o);
                 st_ptx(&red[tid], acc);
             }
             __syncthreads();
@@ -393,11 +393,17 @@ __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __rest
     const uint32_t w = gid / chunks_per_window, t = gid % chunks_per_window;
     const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << CHUNK_LOG);
     PtX running = ptx_identity(), acc = ptx_identity();
+    // running += B_j, then acc += running: one expansion of the addition serves both (its ~55 KB of
+    // straight-line code is most of the instruction cache), the operands are switched around it
 #pragma unroll 1
-    for (uint32_t j = 1u << CHUNK_LOG; j-- > 0;) {
-        const PtX bj = ld_ptx(B + j);
-        ptx_add<MulCall>(running, bj);
-        ptx_add<MulCall>(acc, running);
+    for (uint32_t step = 0; step < (2u << CHUNK_LOG); ++step) {
+        const bool take = (step & 1u) == 0;
+        PtX x = take ? running : acc;
+        PtX y = running;
+        if (take) y = ld_ptx(B + ((1u << CHUNK_LOG) - 1u - (step >> 1)));
+        ptx_add<MulInline>(x, y);
+        if (take) running = x;
+        else acc = x;
     }
     st_ptx(A + gid, acc);
     st_ptx(R + gid, running);
@@ -411,7 +417,7 @@ __device__ __forceinline__ void block_sum(PtX& acc, g1x_xyzz_t* red, uint32_t ti
     for (uint32_t s = lanes >> 1; s > 0; s >>= 1) {
         if (tid < s) {
             const PtX o = ld_ptx(&red[tid + s]);
-            ptx_add<MulCall>(acc, o);
+            ptx_add<MulInline>(acc, o);
             st_ptx(&red[tid], acc);
         }
         __syncthreads();
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void msm_tree_kernel(const g1x_xyzz_t* __restr
         // q > 0: the k-th chunk index with bit `bit` set
         const uint32_t t = q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
         const PtX o = ld_ptx(src + t);
-        ptx_add<MulCall>(acc, o);
+        ptx_add<MulInline>(acc, o);
     }
     block_sum(acc, red, tid, 256);
     if (tid == 0) st_ptx(out + ((size_t)w * nq + q) * parts + part, acc);
