@@ -172,6 +172,21 @@ int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out);
 /* Window width c (bits) the MSM uses for n points: W = ceil(256/c) windows of 2^(c-1) buckets. */
 uint32_t plonk_msm_window_bits(size_t n);
 
+/* Device-time breakdown of the last timed plonk_commit / plonk_commit_dev on this context
+ * (measurement aid, no counterpart in the reference): the sort of the (point, sign) entries by
+ * bucket, the accumulation of oversized buckets (one workgroup each), the bucket accumulation
+ * kernel proper (one lane per bucket), and the reduction of the bucket sums including the copy of
+ * the result to the host; `entries` = number of mixed additions the bucket kernels performed. */
+typedef struct plonk_msm_timing {
+    float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;
+    uint64_t entries;
+    uint32_t window_bits, bucket_sets;
+} plonk_msm_timing;
+/* Timing marks cost extra events on the MSM streams, so they are recorded only between
+ * plonk_msm_set_timing(ctx, 1) and plonk_msm_set_timing(ctx, 0). */
+int32_t plonk_msm_set_timing(plonk_ctx* ctx, int32_t enable);
+int32_t plonk_msm_last_timing(plonk_ctx* ctx, plonk_msm_timing* out);
+
 /* ---- encodings (host only, no device work) ---- */
 /* G1Affine::to_compressed_bytes (curve.rs:84-88). */
 int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]);
@@ -189,7 +204,8 @@ int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_
 
 /* ---- measurement helper: achieved Fr / Fq Montgomery multiplications per second of a
  * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
- * priced against).  which: 0 = Fr, 1 = Fq. */
+ * priced against).  which: 0 = Fr, 1 = Fq in the 29-bit-limb lazy form the kernels multiply in;
+ * 2 = Fr, 3 = Fq in the saturated 32-bit-limb form. */
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second);
 /* HIP-event stopwatch on the ctx stream (the stream every kernel of this ctx runs on): start
  * records an event, stop records a second one, waits for it and returns the elapsed device

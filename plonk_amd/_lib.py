@@ -46,6 +46,11 @@ assert C.sizeof(G1) == 104 and C.sizeof(Fr) == 32
 
 _vp = C.c_void_p
 _sz = C.c_size_t
+class MsmTiming(C.Structure):
+    _fields_ = [("sort_ms", C.c_float), ("big_bucket_ms", C.c_float), ("bucket_ms", C.c_float), ("reduce_ms", C.c_float),
+                ("entries", C.c_uint64), ("window_bits", C.c_uint32), ("bucket_sets", C.c_uint32)]
+
+
 _u32 = C.c_uint32
 _i32 = C.c_int32
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -82,6 +87,8 @@ SIGNATURES = {
     "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "plonk_g1_sum": (_i32, [_vp, _sz, _vp]),
     "plonk_msm_window_bits": (_u32, [_sz]),
+    "plonk_msm_set_timing": (_i32, [_vp, _i32]),
+    "plonk_msm_last_timing": (_i32, [_vp, C.POINTER(MsmTiming)]),
     "plonk_g1_compress": (_i32, [_vp, _vp]),
     "plonk_fr_to_bytes": (_i32, [_vp, _vp]),
     "plonk_fr_from_bytes": (_i32, [_vp, _vp]),

@@ -155,6 +155,16 @@ class Context:
         self.check(lib.plonk_timer_stop(self.h, C.byref(v)))
         return v.value
 
+    def msm_set_timing(self, on):
+        self.check(lib.plonk_msm_set_timing(self.h, 1 if on else 0))
+
+    def msm_last_timing(self):
+        """Device-time breakdown (ms) of the last MSM on this context and its mixed-addition count."""
+        t = _lib.MsmTiming()
+        self.check(lib.plonk_msm_last_timing(self.h, C.byref(t)))
+        return {"sort_ms": t.sort_ms, "big_bucket_ms": t.big_bucket_ms, "bucket_ms": t.bucket_ms, "reduce_ms": t.reduce_ms,
+                "entries": t.entries, "window_bits": t.window_bits, "bucket_sets": t.bucket_sets}
+
     def bench_field_mul(self, which):
         v = C.c_double()
         self.check(lib.plonk_bench_field_mul(self.h, which, C.byref(v)))

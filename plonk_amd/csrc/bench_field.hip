@@ -1,47 +1,66 @@
 // Dependency-chain-free field-multiplication kernels: the integer-VALU ceiling that the NTT,
 // quotient and MSM kernels are priced against.  Each thread runs 4 independent Montgomery
-// product chains so the issue stream is never latency-bound.
+// product chains so the issue stream is never latency-bound.  which = 0 / 1: Fr / Fq in the
+// radix-2^29 form the NTT and MSM kernels multiply in; which = 2 / 3: Fr / Fq in the saturated
+// 32-bit-limb form.
 #include <algorithm>
 #include <vector>
 
 #include "common.hpp"
+#include "fieldx.cuh"
 
 namespace plonk {
 
 template <class F>
-__global__ __launch_bounds__(256) void field_mul_bench_kernel(elem_t<F>* x, int iters) {
+struct SatMul {
+    typedef elem_t<F> elem;
+    static constexpr int WORDS = F::N;
+    static constexpr uint32_t TOP_MASK = 0x0fffffffu, MASK = 0xffffffffu;
+    static __device__ __forceinline__ elem mul(const elem& a, const elem& b) { return f_mul<F>(a, b); }
+};
+template <class X>
+struct LazyMul {
+    typedef xe_t<X> elem;
+    static constexpr int WORDS = X::L;
+    static constexpr uint32_t TOP_MASK = 0x003fffffu, MASK = XMASK;
+    static __device__ __forceinline__ elem mul(const elem& a, const elem& b) { return x_mul<X>(a, b); }
+};
+
+template <class M>
+__global__ __launch_bounds__(256) void field_mul_bench_kernel(typename M::elem* x, int iters) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    elem_t<F> a0 = ld(x + 4 * i), a1 = ld(x + 4 * i + 1), a2 = ld(x + 4 * i + 2), a3 = ld(x + 4 * i + 3);
+    typename M::elem a0 = x[4 * i], a1 = x[4 * i + 1], a2 = x[4 * i + 2], a3 = x[4 * i + 3];
     for (int k = 0; k < iters; ++k) {
-        a0 = f_mul<F>(a0, a1);
-        a1 = f_mul<F>(a1, a2);
-        a2 = f_mul<F>(a2, a3);
-        a3 = f_mul<F>(a3, a0);
+        a0 = M::mul(a0, a1);
+        a1 = M::mul(a1, a2);
+        a2 = M::mul(a2, a3);
+        a3 = M::mul(a3, a0);
     }
-    st(x + 4 * i, a0); st(x + 4 * i + 1, a1); st(x + 4 * i + 2, a2); st(x + 4 * i + 3, a3);
+    x[4 * i] = a0; x[4 * i + 1] = a1; x[4 * i + 2] = a2; x[4 * i + 3] = a3;
 }
 
-template <class F>
+template <class M>
 static double run_bench(Ctx* ctx) {
+    typedef typename M::elem elem;
     const int blocks = 256 * 8, threads = 256, iters = 256;
     const size_t n = (size_t)blocks * threads * 4;
-    DevBuf<elem_t<F>> buf(n);
-    std::vector<elem_t<F>> h(n);
+    DevBuf<elem> buf(n);
+    std::vector<elem> h(n);
     uint64_t s = 0x9E3779B97F4A7C15ull;
     for (size_t i = 0; i < n; ++i)
-        for (int j = 0; j < F::N; ++j) {
+        for (int j = 0; j < M::WORDS; ++j) {
             s = s * 6364136223846793005ull + 1442695040888963407ull;
-            h[i].l[j] = (uint32_t)(s >> 33) & (j == F::N - 1 ? 0x0fffffffu : 0xffffffffu);
+            h[i].l[j] = (uint32_t)(s >> 33) & (j == M::WORDS - 1 ? M::TOP_MASK : M::MASK);
         }
-    HIP_CHECK(hipMemcpy(buf.p, h.data(), n * sizeof(elem_t<F>), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(buf.p, h.data(), n * sizeof(elem), hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(field_mul_bench_kernel<F>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, 8);
+    hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, 8);
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(field_mul_bench_kernel<F>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, iters);
+        hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, iters);
         HIP_CHECK(hipEventRecord(e1, ctx->stream));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -55,7 +74,13 @@ static double run_bench(Ctx* ctx) {
 }
 
 double bench_field_mul(Ctx* ctx, uint32_t which) {
-    return which == 0 ? run_bench<FrP>(ctx) : run_bench<FqP>(ctx);
+    switch (which) {
+        case 0: return run_bench<LazyMul<FrX>>(ctx);
+        case 1: return run_bench<LazyMul<FqX>>(ctx);
+        case 2: return run_bench<SatMul<FrP>>(ctx);
+        case 3: return run_bench<SatMul<FqP>>(ctx);
+        default: throw Error(PLONK_E_INVALID, "bench: unknown field selector");
+    }
 }
 
 }  // namespace plonk

@@ -360,6 +360,23 @@ int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out) {
 
 uint32_t plonk_msm_window_bits(size_t n) { return msm_window_bits(n); }
 
+int32_t plonk_msm_set_timing(plonk_ctx* ctx, int32_t enable) {
+    if (!ctx) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    msm_set_timing(C_, enable != 0);
+    API_END()
+}
+
+int32_t plonk_msm_last_timing(plonk_ctx* ctx, plonk_msm_timing* out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    MsmTiming t;
+    msm_last_timing(C_, &t);
+    out->sort_ms = t.sort_ms; out->big_bucket_ms = t.big_bucket_ms; out->bucket_ms = t.bucket_ms; out->reduce_ms = t.reduce_ms;
+    out->entries = t.entries; out->window_bits = t.window_bits; out->bucket_sets = t.bucket_sets;
+    API_END()
+}
+
 int32_t plonk_timer_start(plonk_ctx* ctx) {
     if (!ctx) return PLONK_E_INVALID;
     API_BEGIN(ctx)
@@ -430,7 +447,7 @@ int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]) {
 }
 
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second) {
-    if (!ctx || !muls_per_second || which > 1) return PLONK_E_INVALID;
+    if (!ctx || !muls_per_second || which > 3) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     *muls_per_second = bench_field_mul(C_, which);
     API_END()

@@ -340,8 +340,16 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
     const uint32_t cnt = counts[gid];
     const uint32_t* src = sorted + offsets[gid];
     PtX acc = ptx_identity();
+    // the next point is fetched (a random 128-byte read) while the current one is added
+    uint32_t e_next = cnt ? src[0] : 0u;
+    AffX nxt = cnt ? load_signed_point(points, e_next) : AffX{x_zero<FqX>(), x_zero<FqX>()};
+    e_next = cnt > 1 ? src[1] : 0u;
     for (uint32_t k = 0; k < cnt; ++k) {
-        const AffX p = load_signed_point(points, src[k]);
+        const AffX p = nxt;
+        if (k + 1 < cnt) {
+            nxt = load_signed_point(points, e_next);
+            if (k + 2 < cnt) e_next = src[k + 2];
+        }
         ptx_madd(acc, p);
     }
     st_ptx(buckets + gid, acc);
@@ -499,7 +507,10 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
 // buckets (integer-VALU bound) and tail (latency-bound reductions) -- so the sort of MSM k+1 and the
 // tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
-    hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;
+    hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;   // order the phases
+    hipEvent_t t_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // timing marks (only when enabled)
+    bool timed = false;
+    uint32_t* host_entries = nullptr;   // pinned: (point, sign) entries of the last run
     DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, part_hist, order, bins;
     DevBuf<uint2> coarse;
     DevBuf<g1x_xyzz_t> buckets, A, R, partial;
@@ -510,6 +521,9 @@ struct MsmSlot {
     bool empty = true;
     ~MsmSlot() {
         if (host_sums) (void)hipHostFree(host_sums);
+        if (host_entries) (void)hipHostFree(host_entries);
+        for (auto& e : t_ev)
+            if (e) (void)hipEventDestroy(e);
         if (sorted_ev) (void)hipEventDestroy(sorted_ev);
         if (buckets_ev) (void)hipEventDestroy(buckets_ev);
         if (done_ev) (void)hipEventDestroy(done_ev);
@@ -518,6 +532,7 @@ struct MsmSlot {
 
 struct MsmWorkspace {
     static constexpr int SLOTS = 3;
+    bool timing = false;   // record the timing marks (msm_set_timing)
     MsmSlot slot[SLOTS];
     hipStream_t sort_stream = nullptr, bucket_stream = nullptr;
     hipEvent_t ready = nullptr;
@@ -539,6 +554,8 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
             HIP_CHECK(hipEventCreateWithFlags(&s.sorted_ev, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s.buckets_ev, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s.done_ev, hipEventDisableTiming));
+            for (auto& e : s.t_ev) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipHostMalloc((void**)&s.host_entries, sizeof(uint32_t), hipHostMallocDefault));
         }
     }
     return static_cast<MsmWorkspace*>(ctx->msm_ws.get());
@@ -603,6 +620,8 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     if (!tail_phase) {
     // ---- sort phase (the caller has ordered the sort stream behind the scalars) ----
     st = ws->sort_stream;
+    s.timed = ws->timing;
+    if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[0], st));
     HIP_CHECK(hipMemsetAsync(s.wg_counts.p + (matrix - 1), 0, sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
@@ -619,14 +638,20 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
     hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p, s.order.p);
+    if (s.timed) {
+        HIP_CHECK(hipMemcpyAsync(s.host_entries, s.wg_offsets.p + (matrix - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(s.t_ev[1], st));
+    }
     HIP_CHECK(hipEventRecord(s.sorted_ev, st));
     // ---- bucket phase ----
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
     hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        s.order.p, n_big, s.buckets.p);
+    if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[2], st));
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        total_buckets, s.order.p, n_big, s.buckets.p);
+    if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[3], st));
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
     return;
     }
@@ -639,6 +664,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     hipLaunchKernelGGL(msm_final_kernel, dim3(S * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)S * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
+    if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[4], st));
     HIP_CHECK(hipEventRecord(s.done_ev, st));
 }
 
@@ -685,6 +711,25 @@ void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_de
         for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], true);
         for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
     }
+}
+
+// Timing marks are recorded only while enabled (extra events on the MSM streams).
+void msm_set_timing(Ctx* ctx, bool on) { msm_workspace(ctx)->timing = on; }
+
+// Phase durations of the most recent MSM that ran on slot 0 with timing enabled, and the number of
+// (point, sign) entries it accumulated.
+void msm_last_timing(Ctx* ctx, MsmTiming* out) {
+    MsmWorkspace* ws = msm_workspace(ctx);
+    MsmSlot& s = ws->slot[0];
+    PLONK_REQUIRE(!s.empty && s.c != 0 && s.timed, "msm timing: no timed MSM has run on this context");
+    HIP_CHECK(hipEventSynchronize(s.t_ev[4]));
+    HIP_CHECK(hipEventElapsedTime(&out->sort_ms, s.t_ev[0], s.t_ev[1]));
+    HIP_CHECK(hipEventElapsedTime(&out->big_bucket_ms, s.t_ev[1], s.t_ev[2]));
+    HIP_CHECK(hipEventElapsedTime(&out->bucket_ms, s.t_ev[2], s.t_ev[3]));
+    HIP_CHECK(hipEventElapsedTime(&out->reduce_ms, s.t_ev[3], s.t_ev[4]));
+    out->entries = *s.host_entries;
+    out->window_bits = s.c;
+    out->bucket_sets = s.W;
 }
 
 void g1_convert_to_xform(Ctx* ctx, const g1_affine_t* in, size_t n, g1x_affine_t* out) {

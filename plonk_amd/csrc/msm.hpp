@@ -33,6 +33,13 @@ uint32_t msm_table_bits(size_t n);
 host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n);
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out);
+struct MsmTiming {
+    float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;
+    uint64_t entries;
+    uint32_t window_bits, bucket_sets;
+};
+void msm_set_timing(Ctx* ctx, bool on);
+void msm_last_timing(Ctx* ctx, MsmTiming* out);
 void g1_convert_to_xform(Ctx* ctx, const g1_affine_t* in, size_t n, g1x_affine_t* out);
 Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n, bool with_table = true);
 Srs* srs_from_tau(Ctx* ctx, const host::fr_h& tau, size_t first, size_t n, bool with_table = true);
