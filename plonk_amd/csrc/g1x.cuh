@@ -65,7 +65,7 @@ __device__ __forceinline__ PtX ptx_identity() {
 }
 
 // 2 * P (dbl-2008-s-1, a = 0)
-__device__ __noinline__ PtX ptx_double(const PtX& p) {
+__device__ __forceinline__ PtX ptx_double(const PtX& p) {
     if (ptx_is_inf(p) || x_is_zero16<FqX>(p.y)) return ptx_identity();
     PtX r;
     const fqx U = x_add<FqX>(p.y, p.y);                       // < 8p
@@ -81,7 +81,7 @@ __device__ __noinline__ PtX ptx_double(const PtX& p) {
     return r;
 }
 
-__device__ __noinline__ PtX ptx_double_affine(const AffX& q) {
+__device__ __forceinline__ PtX ptx_double_affine(const AffX& q) {
     PtX p;
     p.x = q.x; p.y = q.y; p.zz = x_one<FqX>(); p.zzz = x_one<FqX>();
     return ptx_double(p);
