@@ -17,6 +17,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12
 
 
+def pmc_traffic(kernel, run_prefix):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, corrected as profiles/r1_pmc_summary.txt states), or None
+    when there is no measurement of this workload."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        row = table[kernel]
+        return row["hbm_bytes_per_launch"] if row["run"] == run_prefix else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(log_n):
     """The C restatement of the reference's loops (oracle/cref), timed on one host core over a
     bounded sample and scaled to the per-proof operation counts of the reference prover:
@@ -164,7 +176,8 @@ def main():
             # dominant kernel of the proof: the MSM bucket accumulation (about half of the GPU time)
             "roofline": {"kernel": "msm_bucket_kernel (2^%d points, c=%d, %d bucket set(s))" % (k, c, sets), "bound": "hbm",
                          "achieved": round(bucket_rate / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(bucket_rate / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(bucket_rate / HBM_PEAK, 4),
+                         "traffic": pmc_traffic("msm_bucket_kernel", "msm") if (k == 20 and c == 20) else None,
                          "avg_launch_ms": round(tm["bucket_ms"], 4), "algorithmic_bytes_per_launch": bucket_bytes,
                          "note": "integer-VALU bound, not HBM bound: see roofline_valu"},
             "roofline_valu": {"kernel": "msm sort + bucket accumulation + reduction", "bound": "valu",
@@ -175,7 +188,8 @@ def main():
                               "fr_mul_peak_G_per_s": round(fr_peak / 1e9, 2)},
             "roofline_ntt": {"kernel": "ntt_pass_kernel (coset NTT 2^%d = %d sweeps)" % (log4, sweeps), "bound": "hbm",
                              "achieved": round(ntt_rate / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                             "frac": round(ntt_rate / HBM_PEAK, 4), "traffic": None,
+                             "frac": round(ntt_rate / HBM_PEAK, 4),
+                             "traffic": pmc_traffic("ntt_pass_kernel", "ntt") if log4 == 22 else None,
                              "avg_launch_ms": round(ntt_ms / sweeps, 4), "algorithmic_bytes_per_launch": ntt_bytes / sweeps},
         }
         if not args.no_cpu_baseline and world == 1:
