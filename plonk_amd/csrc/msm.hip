@@ -24,9 +24,16 @@
 
 namespace plonk {
 
-static constexpr uint32_t BIG_BUCKET = 192;   // points; above this a bucket gets a workgroup
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
-static constexpr uint32_t ORDER_BINS = 256;   // bucket sizes 0..BIG_BUCKET, then one bin for "big"
+static constexpr uint32_t BIG_BUCKET = 192;   // points; above max(this, 4 x the mean size) a bucket gets a workgroup
+static constexpr uint32_t HUGE_BUCKET = 8192; // points; from max(this, 32 x the mean) on it is cut into pieces
+static constexpr uint32_t HUGE_PIECES = 64;   // pieces per huge bucket, a workgroup each
+static constexpr uint32_t ORDER_BINS = 256;   // "huge", "big", then bucket sizes from the big threshold down to 0
+
+// thresholds of one MSM: a bucket is big above `big`, huge from `huge`; sizes are binned by >> shift
+struct BucketClasses {
+    uint32_t big, huge, shift;
+};
 static constexpr uint32_t CHUNK_LOG = 3;      // buckets per lane in the running-sum step
 
 // signed c-bit digits of a canonical scalar, least significant window first
@@ -272,17 +279,17 @@ __global__ __launch_bounds__(1024) void msm_fine_scatter_kernel(const uint2* __r
 }
 
 // ---- 4. bucket order: buckets sorted by decreasing size, so the lanes of a wave run equally long ----
-__device__ __forceinline__ uint32_t order_bin(uint32_t cnt) {  // bin 0 = big buckets, then sizes BIG..0
-    return cnt > BIG_BUCKET ? 0u : 1u + (BIG_BUCKET - cnt);
+__device__ __forceinline__ uint32_t order_bin(uint32_t cnt, BucketClasses k) {  // bin 0 = huge, 1 = big, then by size
+    return cnt >= k.huge ? 0u : (cnt > k.big ? 1u : 2u + ((k.big - cnt) >> k.shift));
 }
-__global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts,
-                                                              uint32_t total_buckets, uint32_t* __restrict__ bins) {
+__global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t total_buckets,
+                                                              BucketClasses classes, uint32_t* __restrict__ bins) {
     __shared__ uint32_t h[ORDER_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < total_buckets) {
-        atomicAdd(&h[order_bin(counts[gid])], 1u);
+        atomicAdd(&h[order_bin(counts[gid], classes)], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
@@ -300,11 +307,12 @@ __global__ __launch_bounds__(256) void msm_order_scan_kernel(uint32_t* __restric
         __syncthreads();
     }
     bins[tid] = part[tid] - v;  // exclusive start of each bin
-    if (tid == 0) *n_big = v;
+    if (tid == 0) n_big[1] = v;        // number of huge buckets
+    if (tid == 1) n_big[0] = part[1];  // huge + big: where the one-lane-per-bucket part of `order` starts
 }
 __global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* __restrict__ counts,
-                                                                 uint32_t total_buckets, uint32_t* __restrict__ bins,
-                                                                 uint32_t* __restrict__ order) {
+                                                                 uint32_t total_buckets, BucketClasses classes,
+                                                                 uint32_t* __restrict__ bins, uint32_t* __restrict__ order) {
     __shared__ uint32_t h[ORDER_BINS];
     __shared__ uint32_t base[ORDER_BINS];
     h[threadIdx.x] = 0;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* 
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bin = 0, rank = 0;
     if (gid < total_buckets) {
-        bin = order_bin(counts[gid]);
+        bin = order_bin(counts[gid], classes);
         rank = atomicAdd(&h[bin], 1u);
     }
     __syncthreads();
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
                                                           const uint32_t* __restrict__ counts,
                                                           uint32_t total_buckets, const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ n_big, g1x_xyzz_t* __restrict__ buckets) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x + *n_big;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x + n_big[0];
     if (slot >= total_buckets) return;
     const uint32_t gid = order[slot];
     const uint32_t cnt = counts[gid];
@@ -355,37 +363,77 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
     st_ptx(buckets + gid, acc);
 }
 
-// ---- 5b. big buckets: one workgroup per bucket ----
+// sum over the workgroup of the lanes' points, result in lane 0's acc
+__device__ __forceinline__ void block_sum_256(PtX& acc, g1x_xyzz_t* red, uint32_t tid) {
+    st_ptx(&red[tid], acc);
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const PtX o = ld_ptx(&red[tid + s]);
+            ptx_add<MulInline>(acc, o);
+            st_ptx(&red[tid], acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 5b. huge buckets (order[0..n_huge)): HUGE_PIECES workgroups each sum a slice of the bucket's
+//          entries; skewed scalars (0/1/-1 selector-like vectors, or a narrow top window) put a
+//          large share of all points into a handful of buckets ----
+__global__ __launch_bounds__(256) void msm_huge_bucket_kernel(const g1x_affine_t* __restrict__ points,
+                                                               const uint32_t* __restrict__ sorted,
+                                                               const uint32_t* __restrict__ offsets,
+                                                               const uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ n_big, uint32_t max_huge,
+                                                               g1x_xyzz_t* __restrict__ pieces) {
+    __shared__ g1x_xyzz_t red[256];
+    const uint32_t tid = threadIdx.x, piece = blockIdx.x;
+    const uint32_t nhuge = min(n_big[1], max_huge);
+    for (uint32_t item = blockIdx.y; item < nhuge; item += gridDim.y) {
+        const uint32_t gid = order[item];
+        const uint32_t cnt = counts[gid];
+        const uint32_t* src = sorted + offsets[gid];
+        const uint32_t len = (cnt + HUGE_PIECES - 1) / HUGE_PIECES;
+        const uint32_t lo = min(cnt, piece * len), hi = min(cnt, lo + len);
+        PtX acc = ptx_identity();
+        for (uint32_t k = lo + tid; k < hi; k += 256) {
+            const AffX p = load_signed_point(points, src[k]);
+            ptx_madd(acc, p);
+        }
+        block_sum_256(acc, red, tid);
+        if (tid == 0) st_ptx(pieces + (size_t)item * HUGE_PIECES + piece, acc);
+        __syncthreads();
+    }
+}
+
+// ---- 5c. big buckets: one workgroup per bucket; for a huge bucket it adds up the pieces ----
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t* __restrict__ points,
                                                               const uint32_t* __restrict__ sorted,
                                                               const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ counts,
                                                               const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ n_big,
+                                                              const uint32_t* __restrict__ n_big, uint32_t max_huge,
+                                                              const g1x_xyzz_t* __restrict__ pieces,
                                                               g1x_xyzz_t* __restrict__ buckets) {
     __shared__ g1x_xyzz_t red[256];
     const uint32_t tid = threadIdx.x;
-    const uint32_t nbig = *n_big;
+    const uint32_t nbig = n_big[0], nhuge = min(n_big[1], max_huge);
     for (uint32_t item = blockIdx.x; item < nbig; item += gridDim.x) {
         const uint32_t gid = order[item];
-        const uint32_t cnt = counts[gid];
-        const uint32_t* src = sorted + offsets[gid];
         PtX acc = ptx_identity();
-        for (uint32_t k = tid; k < cnt; k += 256) {
-            const AffX p = load_signed_point(points, src[k]);
-            ptx_madd(acc, p);
-        }
-        st_ptx(&red[tid], acc);
-        __syncthreads();
-#pragma unroll 1
-        for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (tid < s) {
-                const PtX o = ld_ptx(&red[tid + s]);
-                ptx_add<MulInline>(acc, o);
-                st_ptx(&red[tid], acc);
+        if (item < nhuge) {
+            if (tid < HUGE_PIECES) acc = ld_ptx(pieces + (size_t)item * HUGE_PIECES + tid);
+        } else {
+            const uint32_t cnt = counts[gid];
+            const uint32_t* src = sorted + offsets[gid];
+            for (uint32_t k = tid; k < cnt; k += 256) {
+                const AffX p = load_signed_point(points, src[k]);
+                ptx_madd(acc, p);
             }
-            __syncthreads();
         }
+        block_sum_256(acc, red, tid);
         if (tid == 0) st_ptx(buckets + gid, acc);
         __syncthreads();
     }
@@ -513,7 +561,7 @@ struct MsmSlot {
     uint32_t* host_entries = nullptr;   // pinned: (point, sign) entries of the last run
     DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, part_hist, order, bins;
     DevBuf<uint2> coarse;
-    DevBuf<g1x_xyzz_t> buckets, A, R, partial;
+    DevBuf<g1x_xyzz_t> buckets, pieces, A, R, partial;
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
     size_t host_cap = 0;
@@ -604,6 +652,15 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     s.order.ensure(total_buckets);
     s.bins.ensure(ORDER_BINS + 4);
     s.buckets.ensure(total_buckets);
+    // size classes relative to the mean bucket size; at most entries / huge buckets can be huge
+    const uint32_t mean = (uint32_t)(((size_t)W * n) / total_buckets);
+    BucketClasses classes;
+    classes.big = std::max(BIG_BUCKET, 4 * mean);
+    classes.huge = std::max(HUGE_BUCKET, 32 * mean);
+    classes.shift = 0;
+    while ((classes.big >> classes.shift) > ORDER_BINS - 3) ++classes.shift;
+    const uint32_t max_huge = (uint32_t)(((size_t)W * n) / classes.huge) + 1;
+    s.pieces.ensure((size_t)max_huge * HUGE_PIECES);
     s.A.ensure(total_chunks);
     s.R.ensure(total_chunks);
     s.partial.ensure((size_t)S * nq * parts);
@@ -635,9 +692,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
                        num_wg, low_bits, s.part_hist.p);
     hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p,
                        s.wg_offsets.p, num_wg, low_bits, total_buckets, s.part_hist.p, s.counts.p, s.offsets.p, s.sorted.p);
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p);
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, s.bins.p, s.order.p);
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p,
+                       s.order.p);
     if (s.timed) {
         HIP_CHECK(hipMemcpyAsync(s.host_entries, s.wg_offsets.p + (matrix - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipEventRecord(s.t_ev[1], st));
@@ -646,8 +704,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     // ---- bucket phase ----
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
+    hipLaunchKernelGGL(msm_huge_bucket_kernel, dim3(HUGE_PIECES, 16), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                       s.counts.p, s.order.p, n_big, max_huge, s.pieces.p);
     hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                       s.order.p, n_big, s.buckets.p);
+                       s.order.p, n_big, max_huge, s.pieces.p, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[2], st));
     hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        total_buckets, s.order.p, n_big, s.buckets.p);
@@ -789,10 +849,11 @@ __global__ __launch_bounds__(256) void g1_shift_level_kernel(const g1_affine_t* 
 static void xyzz_to_affine(Ctx* ctx, const g1_xyzz_t* in, size_t n, fq_t* prefix, g1_affine_t* out);
 
 uint32_t msm_table_bits(size_t n) {
-    // one shared bucket set: aim at ~26-32 points per bucket, W n / 2^(c-1) with W = ceil(256/c)
+    // c = log2 n up to 20: ceil(256/c) is 13 for c = 20 and for c = 21, so a wider window would only
+    // add buckets; larger inputs put more points into each of the 2^19 buckets instead
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    return std::max(12u, std::min(21u, lg));
+    return std::max(12u, std::min(20u, lg));
 }
 
 // Builds srs->px as the window table [W][n]: row w holds 2^(c w) P_i in x-form.  With the table
