@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the NTT / MSM rates at the other sizes")
     args = ap.parse_args()
 
     import numpy as np
@@ -192,6 +193,40 @@ def main():
                              "traffic": pmc_traffic("ntt_pass_kernel", "ntt") if log4 == 22 else None,
                              "avg_launch_ms": round(ntt_ms / sweeps, 4), "algorithmic_bytes_per_launch": ntt_bytes / sweeps},
         }
+        if not args.no_sweep:
+            # stand-alone rates at the other sizes (forward NTT in place; commit of uniform scalars
+            # against a resident SRS of the same size)
+            ntt_sweep, msm_sweep = {}, {}
+            for lg in (16, 20, 22, 24, 26):
+                try:
+                    b = ctx.alloc((1 << lg) * 32)
+                    ctx.upload(b, np.random.default_rng(lg).integers(0, 1 << 62, size=(1 << lg, 4), dtype=np.uint64))
+                    ctx.ntt_dev(b, lg, 0)
+                    ctx.timer_start()
+                    for _ in range(10):
+                        ctx.ntt_dev(b, lg, 0)
+                    ntt_sweep["2^%d" % lg] = round(64.0 * (1 << lg) / (ctx.timer_stop() / 10 * 1e-3) / 1e9, 1)
+                    ctx.free(b)
+                except pa.PlonkError as e:
+                    ntt_sweep["2^%d" % lg] = "failed: %s" % e
+            for lg in (16, 18, 20, 22, 24):
+                try:
+                    m = 1 << lg
+                    s2 = srs if (world == 1 and lg == k) else pa.Srs.from_tau(circ.tau, m - 1, ctx=ctx)
+                    b = ctx.alloc(m * 32)
+                    ctx.upload(b, np.random.default_rng(lg).integers(0, 1 << 62, size=(m, 4), dtype=np.uint64))
+                    s2.commit_dev(b, m)
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        s2.commit_dev(b, m)
+                    msm_sweep["2^%d" % lg] = round(m / ((time.perf_counter() - t1) / 3) / 1e6, 1)
+                    ctx.free(b)
+                    if s2 is not srs:
+                        s2.close()
+                except pa.PlonkError as e:
+                    msm_sweep["2^%d" % lg] = "failed: %s" % e
+            out["ntt_gbps_by_size"] = ntt_sweep
+            out["msm_mpoints_per_s_by_size"] = msm_sweep
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(k)
         print(json.dumps(out), flush=True)

@@ -14,6 +14,9 @@ ctx = pa.Context()
 srs = pa.Srs.from_tau(0x1234567, n - 1)
 rng = np.random.default_rng(k)
 sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+if len(sys.argv) > 3 and sys.argv[3] == "skew":   # selector-like vector: 0 / 1 / -1 / 2
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    sc = pa.fr_to_array([0, 1, R - 1, 2])[rng.integers(0, 4, size=n)]
 dev = C.c_void_p()
 ctx.check(pa._lib.lib.plonk_dev_alloc(ctx.h, n * 32, C.byref(dev)))
 ctx.check(pa._lib.lib.plonk_dev_upload(ctx.h, dev, sc.ctypes.data_as(C.c_void_p), n * 32))
