@@ -34,7 +34,8 @@ static constexpr uint32_t ORDER_BINS = 256;   // "huge", "big", then bucket size
 struct BucketClasses {
     uint32_t big, huge, shift;
 };
-static constexpr uint32_t CHUNK_LOG = 3;      // buckets per lane in the running-sum step
+static constexpr uint32_t CHUNK_LOG_BIG = 3;    // log2 of the buckets per lane in the running-sum step ...
+static constexpr uint32_t CHUNK_LOG_SMALL = 1;  // ... and for small bucket sets, where only the depth of the reduction counts
 
 // signed c-bit digits of a canonical scalar, least significant window first
 struct DigitIter {
@@ -439,24 +440,24 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
     }
 }
 
-// ---- 6a. running sums over chunks of L = 2^CHUNK_LOG buckets: lane (w, t) covers b in (tL, (t+1)L]
+// ---- 6a. running sums over chunks of L = 2^chunk_log buckets: lane (w, t) covers b in (tL, (t+1)L]
 //          A_t = sum (b - tL) B_b,  R_t = sum B_b.   sum_b b B_b = sum_t A_t + L sum_t t R_t ----
 __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __restrict__ buckets, uint32_t nbk,
-                                                         uint32_t chunks_per_window, uint32_t total_chunks,
+                                                         uint32_t chunk_log, uint32_t chunks_per_window, uint32_t total_chunks,
                                                          g1x_xyzz_t* __restrict__ A, g1x_xyzz_t* __restrict__ R) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_chunks) return;
     const uint32_t w = gid / chunks_per_window, t = gid % chunks_per_window;
-    const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << CHUNK_LOG);
+    const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << chunk_log);
     PtX running = ptx_identity(), acc = ptx_identity();
     // running += B_j, then acc += running: one expansion of the addition serves both (its ~55 KB of
     // straight-line code is most of the instruction cache), the operands are switched around it
 #pragma unroll 1
-    for (uint32_t step = 0; step < (2u << CHUNK_LOG); ++step) {
+    for (uint32_t step = 0; step < (2u << chunk_log); ++step) {
         const bool take = (step & 1u) == 0;
         PtX x = take ? running : acc;
         PtX y = running;
-        if (take) y = ld_ptx(B + ((1u << CHUNK_LOG) - 1u - (step >> 1)));
+        if (take) y = ld_ptx(B + ((1u << chunk_log) - 1u - (step >> 1)));
         ptx_add<MulInline>(x, y);
         if (take) running = x;
         else acc = x;
@@ -565,7 +566,7 @@ struct MsmSlot {
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
     size_t host_cap = 0;
-    uint32_t c = 0, W = 0, nq = 0, log_chunks = 0;
+    uint32_t c = 0, W = 0, nq = 0, log_chunks = 0, chunk_log = 0;
     bool empty = true;
     ~MsmSlot() {
         if (host_sums) (void)hipHostFree(host_sums);
@@ -625,13 +626,16 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     const uint32_t S = shared ? 1u : W;   // bucket sets
     const uint32_t nbk = 1u << (c - 1);
     const uint32_t total_buckets = S * nbk;
-    const uint32_t chunks = nbk >> CHUNK_LOG, total_chunks = S * chunks;
+    // large bucket sets: the reduction is work-bound (8 buckets per lane, 2048 chunks per tree
+    // workgroup); small ones: it is a chain of dependent additions, kept as short as possible
+    const bool small_set = total_buckets < (1u << 18);
+    const uint32_t chunk_log = std::min(c - 1, small_set ? CHUNK_LOG_SMALL : CHUNK_LOG_BIG);
+    const uint32_t chunks = nbk >> chunk_log, total_chunks = S * chunks;
     uint32_t log_chunks = 0;
     while ((1u << log_chunks) < chunks) ++log_chunks;
     const uint32_t nq = 1 + log_chunks;
-    const uint32_t parts = std::max(1u, chunks / 2048);
-    PLONK_REQUIRE(parts <= 64, "msm: window too wide for the reduction");
-    s.c = c; s.W = S; s.nq = nq; s.log_chunks = log_chunks;
+    const uint32_t parts = std::min(64u, std::max(1u, chunks / (small_set ? 256u : 2048u)));
+    s.c = c; s.W = S; s.nq = nq; s.log_chunks = log_chunks; s.chunk_log = chunk_log;
     // sort geometry: low_bits of the bucket id are sorted per coarse bin, the rest select the bin
     uint32_t kbits = 0;
     while ((1u << kbits) < total_buckets) ++kbits;
@@ -718,7 +722,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     // ---- tail phase, on the ctx stream (idle while its commitments are in flight) ----
     st = ctx->stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
-    hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunks,
+    hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunk_log, chunks,
                        total_chunks, s.A.p, s.R.p);
     hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, S), dim3(256), 0, st, s.A.p, s.R.p, chunks, parts, nq, s.partial.p);
     hipLaunchKernelGGL(msm_final_kernel, dim3(S * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
@@ -745,7 +749,7 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
             g = host::g1_double(g);
             g = host::g1_add(g, xyzz_to_host(q[1 + i]));
         }
-        for (uint32_t k = 0; k < CHUNK_LOG; ++k) g = host::g1_double(g);
+        for (uint32_t k = 0; k < s.chunk_log; ++k) g = host::g1_double(g);
         g = host::g1_add(g, xyzz_to_host(q[0]));
         acc = host::g1_add(acc, g);
     }
@@ -849,11 +853,12 @@ __global__ __launch_bounds__(256) void g1_shift_level_kernel(const g1_affine_t* 
 static void xyzz_to_affine(Ctx* ctx, const g1_xyzz_t* in, size_t n, fq_t* prefix, g1_affine_t* out);
 
 uint32_t msm_table_bits(size_t n) {
-    // c = log2 n up to 20: ceil(256/c) is 13 for c = 20 and for c = 21, so a wider window would only
-    // add buckets; larger inputs put more points into each of the 2^19 buckets instead
+    // 16 or 20: for both the top window of a 255-bit scalar is 15 bits wide, so no window crowds its
+    // digits into a handful of buckets.  ceil(256/c) is 13 for c = 20 and for c = 21, so a wider
+    // window would only add buckets; larger inputs put more points into each of the 2^19 buckets.
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    return std::max(12u, std::min(20u, lg));
+    return lg <= 16 ? 16u : 20u;
 }
 
 // Builds srs->px as the window table [W][n]: row w holds 2^(c w) P_i in x-form.  With the table
