@@ -2,7 +2,7 @@
 
 One step = one proof (plonk_prove_3wire_dev) of the synthetic 2^k-gate circuit, witness resident
 in HBM.  N > 1: one process per GPU (torch.distributed / RCCL); every rank holds the full key, the
-nine commitment MSMs are sharded by point range and their partial sums exchanged (see DESIGN.md).
+nine commitment MSMs are sharded by point range and their partial sums exchanged.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -168,7 +168,7 @@ def main():
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 (Fr / Fq Montgomery residues; multiplied as 9 / 14 limbs of 29 bits in 64-bit accumulators)",
             "data": "synthetic",
-            "config": {"workload": "synthetic 2^%d-gate mul/add chain (BASELINE configs[3]), 3-wire PLONK prove, witness "
+            "config": {"workload": "synthetic 2^%d-gate mul/add chain, 3-wire PLONK prove, witness "
                                    "resident in HBM, SRS/proving key preloaded" % k,
                        "parallelism": "1 GPU" if world == 1 else "msm point-range sharding over %d GPUs, partial sums all-gathered" % world,
                        "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest},

@@ -1,6 +1,6 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle: bit-exact everywhere.
 Small sizes against the Python oracle and the committed golden fixtures, larger ones against the
-C restatement, full BASELINE sizes through size-independent properties."""
+C restatement, the full benchmark sizes through size-independent properties."""
 import ctypes as C
 import hashlib
 import random
@@ -89,7 +89,7 @@ def test_ntt_matches_c_restatement(ctx, log_n, flags):
 
 @pytest.mark.parametrize("log_n", [22, 24])
 def test_ntt_full_size_properties(ctx, log_n):
-    """BASELINE sizes (4n for n = 2^20, and 2^24): round trips, linearity, known transforms."""
+    """Benchmark sizes (4n for n = 2^20, and 2^24): round trips, linearity, known transforms."""
     import plonk_amd as pa
     n = 1 << log_n
     rng = np.random.default_rng(log_n)
@@ -337,7 +337,7 @@ def test_prover_error_behaviour(ctx):
 
 @pytest.mark.parametrize("k", [14, 16])
 def test_prove_large_golden(ctx, k):
-    """Synthetic 2^14 / 2^16-gate circuits (BASELINE config 3): byte-identical to the oracle's proof."""
+    """Synthetic 2^14 / 2^16-gate circuits (the 2^16-gate benchmark configuration and a smaller one): byte-identical to the oracle's proof."""
     import plonk_amd as pa
     es = [e for e in golden("proofs.json") if e["name"] == "synthetic_2^%d" % k]
     if not es:
@@ -352,7 +352,7 @@ def test_prove_large_golden(ctx, k):
 
 
 def test_prove_full_size_verifies(ctx):
-    """BASELINE config 4 (2^20 gates): the proof passes the oracle's verifier (verifier.rs:42-314)
+    """The 2^20-gate benchmark configuration: the proof passes the oracle's verifier (verifier.rs:42-314)
     against the verification key the device computed, a tampered evaluation is rejected, and the
     proof bytes match the digest every earlier build of this prover produced for this input
     (the 2^14 / 2^16 cases above pin the same code path byte-for-byte on the oracle)."""
