@@ -193,6 +193,14 @@ def main():
                              "traffic": pmc_traffic("ntt_pass_kernel", "ntt") if log4 == 22 else None,
                              "avg_launch_ms": round(ntt_ms / sweeps, 4), "algorithmic_bytes_per_launch": ntt_bytes / sweeps},
         }
+        if world == 1:
+            # the same proof from host witness vectors (3 n 32 bytes over PCIe inside the call): never `value`
+            hp = pa.Prover(circ.wires, pk, srs, resident=False)
+            hp.prove([], circ.blinding)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                hp.prove([], circ.blinding)
+            out["prover_ms_host_witness"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
         if not args.no_sweep:
             # stand-alone rates at the other sizes (forward NTT in place; commit of uniform scalars
             # against a resident SRS of the same size)

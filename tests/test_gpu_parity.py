@@ -375,3 +375,29 @@ def test_prove_full_size_verifies(ctx):
     bad = dict(proof.to_dict())
     bad["a_eval"] = (bad["a_eval"] + 1) % R_MOD
     assert not P.verify(vk, _S, bad, [])
+
+
+def test_msm_window_table_degenerate_points(ctx):
+    """SRS large enough for the window table whose points repeat (G, G, -G, 2G, identity ...): buckets
+    then meet equal points (doubling), opposite points (identity) and the identity itself, in every
+    row of the table.  Expected value by linearity: sum s_i k_i * G."""
+    import plonk_amd as pa
+    n = 1 << 14
+    G = curve.G1_GEN
+    base = [G, G, curve.to_affine(curve.jac_neg(curve.to_jac(G))), curve.to_affine(curve.scalar_mul(G, 2)), None, G]
+    ks = [1, 1, R_MOD - 1, 2, 0, 1]
+    pts = [base[i % 6] for i in range(n)]
+    srs = pa.Srs.from_points(pts)
+    rng = random.Random(77)
+    cases = {
+        "uniform": [rng.randrange(R_MOD) for _ in range(n)],
+        "all_one": [1] * n,
+        "all_minus_one": [R_MOD - 1] * n,
+        "zero": [0] * n,
+        "single": [0] * (n - 1) + [12345],
+        "small": [rng.randrange(4) for _ in range(n)],
+    }
+    for name, sc in cases.items():
+        total = sum(s * ks[i % 6] for i, s in enumerate(sc)) % R_MOD
+        want = curve.to_affine(curve.scalar_mul(G, total)) if total else None
+        assert pa.Commitment.commit(sc, srs).point == want, name
