@@ -66,6 +66,7 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;               // plonk_timer_start / _stop
     std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9
     DevBuf<fr_t> ntt_tmp;                                  // intermediate image of a multi-pass NTT
+    bool ntt_lds_attr_set = false;                         // dynamic-LDS limit of ntt_pass_kernel raised
     std::shared_ptr<void> msm_ws;                          // MsmWorkspace (msm.hip)
     std::shared_ptr<void> prover_ws;                       // ProverWorkspace (prover.hip)
     ~Ctx();

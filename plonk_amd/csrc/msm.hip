@@ -1,18 +1,19 @@
 // Multi-scalar multiplication over BLS12-381 G1 for gfx950: the device side of
 // G1Projective::msm (backend_new/src/curve.rs:169-173) and Commitment::commit (kzg.rs:231-245).
 //
-// Pippenger bucket method with signed c-bit digits:
-//   1. digits   : scalar -> canonical form -> W = ceil(256/c) signed digits in [-2^(c-1), 2^(c-1)];
-//                 per-(window, |digit|) histogram.
-//   2. scan     : exclusive prefix sum of the histogram, one workgroup per window.
-//   3. scatter  : point indices grouped by (window, |digit|); bit 31 carries the digit's sign.
-//   4. buckets  : one lane per bucket sums its points with XYZZ mixed additions; buckets larger
-//                 than BIG_BUCKET are summed by a whole workgroup instead (skewed scalars such as
-//                 0/1/-1 selector vectors put most points of a window into one bucket).
-//   5. reduce   : sum_b b * B_b per window: lanes take chunks of L buckets (running sums), lift
-//                 their chunk by (t*L) * chunk_sum with double-and-add, then a tree over LDS.
-//   6. the W window sums are combined (c doublings each) and normalised on the host: O(256)
-//      point operations.
+// Pippenger bucket method with signed c-bit digits in [-2^(c-1), 2^(c-1)], W = ceil(256/c) windows:
+//   1. sort     : the (point, sign) entries of all windows are grouped by bucket with a two-level
+//                 counting sort in LDS (coarse bins per slab of scalars, then each bin by its low
+//                 bits); digits are recomputed from the scalars, never stored.
+//   2. order    : buckets are listed by decreasing size, so the lanes of a wave run equally long.
+//   3. buckets  : one lane per bucket sums its points with XYZZ mixed additions; buckets far above
+//                 the mean size are summed by a whole workgroup, the largest in 64 pieces (skewed
+//                 scalars such as 0/1/-1 selector vectors put most points of a window into one bucket).
+//   4. reduce   : sum_b b * B_b: lanes take chunks of L buckets (running sums A_t, R_t), then
+//                 sum A_t and the bit-masked sums of R_t by LDS trees (sum_t t R_t = sum_i 2^i G_i).
+//   5. the few resulting points are combined and normalised on the host: O(100) point operations.
+// An SRS of >= 2^14 points carries a table of its points times 2^(c w): all windows then share ONE
+// bucket set, so steps 3-4 run over 2^(c-1) buckets once instead of once per window.
 // Integer VALU work throughout; bytes moved are negligible next to the field multiplications.
 #include <algorithm>
 #include <vector>

@@ -49,12 +49,15 @@ struct NttPassArgs {
     const frx_slot* pre;     // [2^R] multiplies input digit d (nullable)
     const frx_slot* post;    // [2^R] multiplies output digit k (nullable)
     const frx_slot* sub_tw;  // w_{2^11}^j
-    const frx_slot* tw_lo;   // w_N^j, j < 2^logL
-    const frx_slot* tw_hi;   // w_N^(j << logL)
-    uint32_t log_n, R, log_s, log_c, log_h, log_l;
+    // step twiddles of a non-last sweep p: one table per later sweep q, entry [i_q][k_p] =
+    // w_N^(k_p M_p * i_q S_q) (times the coset factors that depend on i_q or k_p alone)
+    const frx_slot* pair_tab[NTT_MAX_PASSES - 1];
+    uint32_t pair_shift[NTT_MAX_PASSES - 1];   // log2 S_q: where i_q sits in the lower index
+    uint32_t pair_mask[NTT_MAX_PASSES - 1];    // N_q - 1
+    uint32_t n_pairs;
+    uint32_t log_n, R, log_s, log_c, log_h;
     uint32_t n_prev;              // number of earlier sweeps
     uint32_t r_prev[NTT_MAX_PASSES];
-    uint32_t log_s_next;          // log2 S_{p+1} (non-last sweeps)
     uint32_t is_last;
     uint64_t batch_stride;
 };
@@ -228,7 +231,6 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     }
 
     // ---- store ----
-    const uint32_t K_hi = p.is_last ? 0u : digits_rev(hi, p.log_h, p.n_prev, p.r_prev);
     for (uint32_t e = tid; e < T; e += NTT_THREADS) {
         const uint32_t c = e & (C - 1);
         const uint32_t k = e >> log_c;
@@ -242,15 +244,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             if (!p.post) x = x_mul<FrX>(x, x_one<FrX>());   // below 2p, same residue
             x = x_canon2<FrX>(x);   // the transform's output is canonical
         } else {
-            // twiddle w_N^(i_next * S_next * K_p),  K_p = K_hi + 2^log_h * k
+            // step twiddles: for every later sweep q the factor w_N^(k M_p * i_q S_q), i_q read off
+            // the lower index (this is also what brings the element back below 2p)
             const uint32_t lo = lo_base + c;
-            const uint64_t inext_s = (uint64_t)(lo >> p.log_s_next) << p.log_s_next;
-            const uint64_t Kp = (uint64_t)K_hi + ((uint64_t)k << p.log_h);
-            const uint64_t ex = (inext_s * Kp) & (((uint64_t)1 << p.log_n) - 1);
-            // (also what brings the element back below 2p, so it is not skipped for ex == 0)
-            const frx wl = ld_tw(p.tw_lo + (ex & ((1u << p.log_l) - 1u)));
-            const frx wh = ld_tw(p.tw_hi + (ex >> p.log_l));
-            x = x_mul<FrX>(x, x_mul<FrX>(wl, wh));
+#pragma unroll 1
+            for (uint32_t j = 0; j < p.n_pairs; ++j) {
+                const uint32_t iq = (lo >> p.pair_shift[j]) & p.pair_mask[j];
+                x = x_mul<FrX>(x, ld_tw(p.pair_tab[j] + (((size_t)iq << R) + k)));
+            }
             addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
         }
         st(out + addr, x_repack_out<FrX>(x));
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
 struct NttPlan {
     uint32_t log_n = 0, flags = 0, n_pass = 0;
     uint32_t R[NTT_MAX_PASSES] = {0, 0, 0, 0};
-    uint32_t log_l = 0;
-    DevBuf<frx_slot> sub_tw, tw_lo, tw_hi;
-    DevBuf<frx_slot> pre[NTT_MAX_PASSES], post[NTT_MAX_PASSES];
+    DevBuf<frx_slot> sub_tw;
+    DevBuf<frx_slot> pair[NTT_MAX_PASSES][NTT_MAX_PASSES];   // [p][q], p < q: step twiddles
+    DevBuf<frx_slot> pre, post;   // first sweep's input scale (forward coset), last sweep's output scale (inverse)
     host::fr_h shift;
 };
 
@@ -325,35 +326,52 @@ static std::unique_ptr<NttPlan> build_plan(uint32_t log_n, uint32_t flags, const
         if (inverse) w11 = Fr::inv(w11);
         upload(pl->sub_tw, powers(w11, (size_t)1 << (NTT_SUBTW_LOG - 1)));
     }
-    if (P > 1) {
-        pl->log_l = (log_n + 1) / 2;
-        upload(pl->tw_lo, powers(w, (size_t)1 << pl->log_l));
-        upload(pl->tw_hi, powers(Fr::pow_u64(w, (uint64_t)1 << pl->log_l), (size_t)1 << (log_n - pl->log_l)));
-    }
-    // per-digit scale tables
-    host::fr_h n_inv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
-    if (coset && !inverse) {
-        // coefficient i is scaled by g^i (fft.rs:129-133); i = sum_p d_p * S_p
-        uint32_t log_s = log_n;
+    // index algebra: input index = sum_q i_q S_q, output index = sum_p k_p M_p
+    uint32_t log_S[NTT_MAX_PASSES], log_M[NTT_MAX_PASSES];
+    {
+        uint32_t ls = log_n, lm = 0;
         for (uint32_t p = 0; p < P; ++p) {
-            log_s -= pl->R[p];
-            upload(pl->pre[p], powers(Fr::pow_u64(shift, (uint64_t)1 << log_s), (size_t)1 << pl->R[p]));
+            ls -= pl->R[p];
+            log_S[p] = ls;
+            log_M[p] = lm;
+            lm += pl->R[p];
         }
     }
+    const host::fr_h n_inv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
+    const host::fr_h g_inv = coset ? Fr::inv(shift) : Fr::one();
+    // forward coset: coefficient i is scaled by g^i (fft.rs:129-133), i = sum_q i_q S_q.  The factor of
+    // the first digit multiplies the input of the first sweep; that of digit q > 0 rides on the step
+    // twiddles applied after sweep q-1.
+    if (coset && !inverse) upload(pl->pre, powers(Fr::pow_u64(shift, (uint64_t)1 << log_S[0]), (size_t)1 << pl->R[0]));
+    // inverse: output K is scaled by 1/n (fft.rs:52-56) and, for the coset form, g^-K (fft.rs:147-152),
+    // K = sum_p k_p M_p.  The factor of the last digit (and 1/n) multiplies the output of the last
+    // sweep; that of digit p < P-1 rides on the step twiddles applied after sweep p.
     if (inverse) {
-        // output K is scaled by 1/n (fft.rs:52-56) and, for the coset form, g^-K (fft.rs:147-152);
-        // K = sum_p k_p * 2^(R_1+..+R_{p-1})
-        host::fr_h g_inv = coset ? Fr::inv(shift) : Fr::one();
-        uint32_t log_m = 0;
-        for (uint32_t p = 0; p < P; ++p) {
-            const bool last = p + 1 == P;
-            if (coset || last) {
-                std::vector<host::fr_h> v = powers(Fr::pow_u64(g_inv, (uint64_t)1 << log_m), (size_t)1 << pl->R[p]);
-                if (last)
-                    for (auto& x : v) x = Fr::mul(x, n_inv);
-                upload(pl->post[p], v);
+        std::vector<host::fr_h> v = powers(Fr::pow_u64(g_inv, (uint64_t)1 << log_M[P - 1]), (size_t)1 << pl->R[P - 1]);
+        for (auto& x : v) x = Fr::mul(x, n_inv);
+        upload(pl->post, v);
+    }
+    for (uint32_t p = 0; p + 1 < P; ++p) {
+        for (uint32_t q = p + 1; q < P; ++q) {
+            const size_t np = (size_t)1 << pl->R[p], nq = (size_t)1 << pl->R[q];
+            std::vector<host::fr_h> t(np * nq);
+            // w^(M_p S_q) has order N / (M_p S_q) >= N_p N_q ... only products k i < N_p N_q occur
+            const host::fr_h step = Fr::pow_u64(w, (uint64_t)1 << (log_M[p] + log_S[q]));
+            const bool neighbours = q == p + 1;
+            const host::fr_h gi = (coset && !inverse && neighbours) ? Fr::pow_u64(shift, (uint64_t)1 << log_S[q]) : Fr::one();
+            const host::fr_h gk = (coset && inverse && neighbours) ? Fr::pow_u64(g_inv, (uint64_t)1 << log_M[p]) : Fr::one();
+            const std::vector<host::fr_h> gk_pow = powers(gk, np);
+            host::fr_h base = Fr::one(), gi_pow = Fr::one();   // step^i, gi^i
+            for (size_t i = 0; i < nq; ++i) {
+                host::fr_h acc = gi_pow;                        // step^(i k) * gi^i, k = 0
+                for (size_t k = 0; k < np; ++k) {
+                    t[i * np + k] = Fr::mul(acc, gk_pow[k]);
+                    acc = Fr::mul(acc, base);
+                }
+                base = Fr::mul(base, step);
+                gi_pow = Fr::mul(gi_pow, gi);
             }
-            log_m += pl->R[p];
+            upload(pl->pair[p][q], t);
         }
     }
     return pl;
@@ -379,11 +397,10 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
 static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride) {
     const uint32_t log_n = pl->log_n, P = pl->n_pass;
     if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->ntt_lds_attr_set) {   // per device, and a context belongs to one device
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        attr_set = true;
+        ctx->ntt_lds_attr_set = true;
     }
     fr_t* tmp = nullptr;
     if (P > 1) {
@@ -401,20 +418,26 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
         memset(&a, 0, sizeof(a));
         a.in = (p == 0) ? data : tmp;
         a.out = last ? data : tmp;
-        a.pre = pl->pre[p].p;
-        a.post = pl->post[p].p;
+        a.pre = p == 0 ? pl->pre.p : nullptr;
+        a.post = last ? pl->post.p : nullptr;
         a.sub_tw = pl->sub_tw.p;
-        a.tw_lo = pl->tw_lo.p;
-        a.tw_hi = pl->tw_hi.p;
+        a.n_pairs = P - 1 - p;
+        {
+            uint32_t ls = log_s;   // log2 S_p; S_q for q > p follows by peeling R[q]
+            for (uint32_t q = p + 1; q < P; ++q) {
+                ls -= pl->R[q];
+                a.pair_tab[q - p - 1] = pl->pair[p][q].p;
+                a.pair_shift[q - p - 1] = ls;
+                a.pair_mask[q - p - 1] = (1u << pl->R[q]) - 1u;
+            }
+        }
         a.log_n = log_n;
         a.R = R;
         a.log_s = log_s;
         a.log_h = log_h;
-        a.log_l = pl->log_l;
         a.n_prev = p;
         for (uint32_t q = 0; q < p; ++q) a.r_prev[q] = pl->R[q];
         a.is_last = last ? 1u : 0u;
-        a.log_s_next = last ? 0u : (log_s - pl->R[p + 1]);
         a.batch_stride = batch_stride;
         uint32_t log_c = NTT_TILE_LOG > R ? NTT_TILE_LOG - R : 0;
         if (last) log_c = p ? std::min(log_c, pl->R[0]) : 0u;
