@@ -5,14 +5,17 @@
 // after).  The reference runs log2(N) radix-2 sweeps over the whole vector; here a transform of
 // N = N_1 * ... * N_P points is P sweeps over HBM.  Sweep p loads tiles of N_p x C elements
 // into LDS (C consecutive elements per row, so every global access is a C*32-byte run), runs
-// log2(N_p) radix-2 decimation-in-frequency stages out of LDS, applies the step's twiddle
-// w_N^(i_{p+1} * S_{p+1} * K_p) and stores.  The first sweep reads `data` and writes the
-// intermediate image, the last reads that image and writes natural order back to `data`.
+// log2(N_p) radix-2 stages out of LDS, applies the step twiddles and stores.  The first sweep
+// reads `data` and writes the intermediate image, the last reads that image and writes natural
+// order back to `data`.
 //
 // Index algebra: address = hi * (N_p * S_p) + d * S_p + lo with S_p = N_{p+1}...N_P; sweep p
 // replaces digit d = i_p by k_p.  hi holds k_1..k_{p-1} (k_1 most significant), lo holds
-// i_{p+1}..i_P.  K_p = k_1 + N_1 k_2 + ... + N_1..N_{p-1} k_p.  The output index of the whole
-// transform is K_P.
+// i_{p+1}..i_P.  With M_p = N_1...N_{p-1} the input index is sum_q i_q S_q, the output index
+// sum_p k_p M_p, and w_N^(input * output) factors into the sweeps' own transforms (q = p) and, for
+// every pair p < q, the step twiddle w_N^(k_p M_p * i_q S_q): after sweep p an element is multiplied
+// by one table entry [i_q][k_p] for each later sweep q.  Coset factors g^(i_q S_q) / g^(-k_p M_p)
+// depend on one digit only and ride on the tables of neighbouring sweeps.
 #include <algorithm>
 
 #include "common.hpp"
