@@ -56,6 +56,21 @@ def test_ntt_reference_interface_and_kats(ctx):
         pa.fft([1] * 5, w4, 4)
 
 
+@pytest.mark.parametrize("log_n", [6, 11, 13, 14])
+def test_ntt_arbitrary_coset_shift(ctx, log_n):
+    """coset_fft / coset_ifft with generators other than 7 (fft.rs:121-157 take any k), at sizes of
+    one, two and three sweeps; switching the generator back and forth must rebuild the tables."""
+    import plonk_amd as pa
+    n = 1 << log_n
+    v = _rand(500 + log_n, n)
+    w = root_of_unity(n)
+    for shift in (5, 7, R_MOD - 2, 0x1234567890ABCDEF1234567890ABCDEF):
+        fwd = pa.fr_from_array(ctx.ntt(pa.fr_to_array(v), 2, shift=shift))
+        assert fwd == offt.coset_fft(v, w, shift, n), (log_n, shift)
+        back = pa.fr_from_array(ctx.ntt(pa.fr_to_array(fwd), 3, shift=shift))
+        assert back == v, (log_n, shift)
+
+
 def test_ntt_golden(ctx):
     import plonk_amd as pa
     for e in golden("ntt.json"):
@@ -241,7 +256,39 @@ def _gpu_case(cs, perm, tau):
 VK_KEYS = ("q_m", "q_l", "q_r", "q_o", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "rp42_pi", "rp0", "synthetic6", "synthetic10"])
+def _public_input_circuit(k):
+    """2^k gates: two public-input gates (constraint.rs:198-210: q_L = 1, a = PI, marked with
+    mark_public_input :353-357) feeding a mul/add chain through copy constraints."""
+    rng = random.Random(4242 + k)
+    n = 1 << k
+    cs = P.ConstraintSystem()
+    pis = [rng.randrange(R_MOD), rng.randrange(R_MOD)]
+    for i, v in enumerate(pis):
+        g = P.Gate(q_l=1)
+        g.a, g.b, g.c = v, 0, 0
+        cs.add_gate(g)
+        cs.public_input_positions.append(i)
+    a, b = pis
+    g = P.Gate.mul(); g.a, g.b, g.c = a, b, a * b % R_MOD
+    cs.add_gate(g)
+    cs.add_copy_constraint((P.WIRE_A, 0), (P.WIRE_A, 2))
+    cs.add_copy_constraint((P.WIRE_A, 1), (P.WIRE_B, 2))
+    acc = g.c
+    for i in range(3, n):
+        b = rng.randrange(R_MOD)
+        if i % 2:
+            g = P.Gate.add(); c = (acc + b) % R_MOD
+        else:
+            g = P.Gate.mul(); c = acc * b % R_MOD
+        g.a, g.b, g.c = acc, b, c
+        cs.add_gate(g)
+        cs.add_copy_constraint((P.WIRE_C, i - 1), (P.WIRE_A, i))
+        acc = c
+    cs.finalize()
+    return cs, pis
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "rp42_pi", "rp0", "synthetic6", "synthetic10", "pi_gates4", "pi_gates9"])
 def test_prove_matches_oracle_bytes(ctx, name):
     import plonk_amd as pa
     bl = _rand(98, 11)
@@ -255,6 +302,9 @@ def test_prove_matches_oracle_bytes(ctx, name):
         cs, pis = P.range_proof_circuit(8, 42), [42]
     elif name == "rp0":
         cs = P.range_proof_circuit(8, 0)
+    elif name.startswith("pi_gates"):
+        cs, pis = _public_input_circuit(int(name[len("pi_gates"):]))
+        assert cs.public_input_positions == [0, 1]
     else:
         k = int(name[len("synthetic"):])
         cs, bl = P.synthetic_circuit(k)
