@@ -451,3 +451,24 @@ def test_msm_window_table_degenerate_points(ctx):
         total = sum(s * ks[i % 6] for i, s in enumerate(sc)) % R_MOD
         want = curve.to_affine(curve.scalar_mul(G, total)) if total else None
         assert pa.Commitment.commit(sc, srs).point == want, name
+
+
+def test_msm_timing_hook(ctx):
+    """plonk_msm_set_timing / plonk_msm_last_timing: phase times of one commit and its addition count."""
+    import plonk_amd as pa
+    n = 1 << 14
+    srs = pa.Srs.from_tau(987654321, n - 1)
+    sc = np.random.default_rng(3).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    dev = ctx.alloc(n * 32)
+    ctx.upload(dev, sc)
+    with pytest.raises(pa.PlonkError):
+        ctx.msm_last_timing()          # nothing timed yet on this context's slot
+    ctx.msm_set_timing(True)
+    srs.commit_dev(dev, n)
+    t = ctx.msm_last_timing()
+    ctx.msm_set_timing(False)
+    ctx.free(dev)
+    assert t["window_bits"] == pa.api.msm_window_bits(n) or t["bucket_sets"] == 1
+    windows = -(-256 // t["window_bits"])
+    assert 0.99 * windows * n <= t["entries"] <= windows * n      # zero digits are skipped
+    assert all(t[key] > 0 for key in ("sort_ms", "bucket_ms", "reduce_ms")) and t["big_bucket_ms"] >= 0
