@@ -482,42 +482,90 @@ __device__ __forceinline__ void block_sum(PtX& acc, g1x_xyzz_t* red, uint32_t ti
     }
 }
 
-// ---- 6b. tree sums.  quantity q = 0: sum_t A_t;  q = i + 1: G_i = sum of R_t over the chunks t with
-//          bit i set (so that sum_t t R_t = sum_i 2^i G_i); only those chunks are visited.  Workgroup
-//          (q, part) sums its share of the chunks. ----
-__global__ __launch_bounds__(256) void msm_tree_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
-                                                        uint32_t chunks_per_window, uint32_t parts, uint32_t nq,
-                                                        g1x_xyzz_t* __restrict__ out) {
-    __shared__ g1x_xyzz_t red[256];
-    const uint32_t part = blockIdx.x % parts, q = blockIdx.x / parts, w = blockIdx.y, tid = threadIdx.x;
-    const g1x_xyzz_t* src = (q == 0 ? A : R) + (size_t)w * chunks_per_window;
-    const uint32_t count = q == 0 ? chunks_per_window : chunks_per_window >> 1;
-    const uint32_t span = (count + parts - 1) / parts;
-    const uint32_t lo = min(count, part * span), hi = min(count, lo + span);
-    const uint32_t bit = q == 0 ? 0u : q - 1u;
+// ---- 6b/6c. sum_t A_t and the bit-masked sums G_i = sum of R_t over the chunks t with bit i set (so
+//          that sum_t t R_t = sum_i 2^i G_i), through the view t = hi * 2^ml + lo of the chunk index:
+//          a low bit of t is a bit of lo, so its G_i is a masked sum of the 2^ml column sums
+//          Col_lo = sum_hi R[hi][lo]; a high bit is a bit of hi and goes through the row sums
+//          Row_hi = sum_lo R[hi][lo].  Two adds per chunk instead of one per chunk and bit.
+//          6b: one wave per row (R and A) or column; 6c: one workgroup per quantity. ----
+// Sum of `count` points src[index(k)] over a workgroup of LANES lanes: every lane first adds its
+// share, then the lanes' sums are folded through LDS.  Both phases go through ONE expansion of the
+// point addition: in these short kernels most of the time is the first pass over its ~55 KB of
+// straight-line code, so a second copy would nearly double the run time.  Result in lane 0.
+template <uint32_t LANES, class Index>
+__device__ __forceinline__ PtX reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
+                                             g1x_xyzz_t* red, uint32_t tid) {
+    const uint32_t n_serial = (count + LANES - 1) / LANES;
+    uint32_t levels = 0;
+    while ((1u << levels) < LANES) ++levels;
     PtX acc = ptx_identity();
 #pragma unroll 1
-    for (uint32_t k = lo + tid; k < hi; k += 256) {
-        // q > 0: the k-th chunk index with bit `bit` set
-        const uint32_t t = q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
-        const PtX o = ld_ptx(src + t);
-        ptx_add<MulInline>(acc, o);
+    for (uint32_t step = 0; step < n_serial + levels; ++step) {
+        PtX o = ptx_identity();
+        if (step < n_serial) {
+            const uint32_t k = tid + step * LANES;
+            if (k < count) o = ld_ptx(src + index(k));
+        } else {
+            const uint32_t half = LANES >> (step - n_serial + 1);
+            st_ptx(&red[tid], acc);
+            __syncthreads();
+            if (tid < half) o = ld_ptx(&red[tid + half]);
+            __syncthreads();
+        }
+        ptx_add<MulInline>(acc, o);   // adding the identity returns at once
     }
-    block_sum(acc, red, tid, 256);
-    if (tid == 0) st_ptx(out + ((size_t)w * nq + q) * parts + part, acc);
+    return acc;
 }
 
-// ---- 6c. sum the `parts` (<= 64) partials of each (window, quantity) and convert to the saturated form ----
-__global__ __launch_bounds__(64) void msm_final_kernel(const g1x_xyzz_t* __restrict__ partial, uint32_t parts,
-                                                        g1_xyzz_t* __restrict__ out) {
+__global__ __launch_bounds__(64) void msm_rowcol_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
+                                                         uint32_t m, uint32_t ml, g1x_xyzz_t* __restrict__ row,
+                                                         g1x_xyzz_t* __restrict__ arow, g1x_xyzz_t* __restrict__ col) {
     __shared__ g1x_xyzz_t red[64];
-    const uint32_t item = blockIdx.x, tid = threadIdx.x;
-    PtX acc = tid < parts ? ld_ptx(partial + (size_t)item * parts + tid) : ptx_identity();
-    block_sum(acc, red, tid, 64);
+    const uint32_t rows = 1u << (m - ml), cols = 1u << ml, chunks = 1u << m;
+    const uint32_t w = blockIdx.y, tid = threadIdx.x;
+    uint32_t job = blockIdx.x;
+    const g1x_xyzz_t* src;
+    g1x_xyzz_t* dst;
+    uint32_t first, stride, count;
+    if (job < 2 * rows) {            // a row of R (job < rows) or of A: 2^ml consecutive chunks
+        const bool of_a = job >= rows;
+        if (of_a) job -= rows;
+        src = (of_a ? A : R) + (size_t)w * chunks;
+        dst = (of_a ? arow : row) + (size_t)w * rows + job;
+        first = job << ml; stride = 1; count = cols;
+    } else {                         // a column of R: every 2^ml-th chunk
+        job -= 2 * rows;
+        src = R + (size_t)w * chunks;
+        dst = col + (size_t)w * cols + job;
+        first = job; stride = cols; count = rows;
+    }
+    const PtX acc = reduce_points<64>(src, count, [=](uint32_t k) { return first + (size_t)k * stride; }, red, tid);
+    if (tid == 0) st_ptx(dst, acc);
+}
+
+__global__ __launch_bounds__(256) void msm_masked_kernel(const g1x_xyzz_t* __restrict__ row, const g1x_xyzz_t* __restrict__ arow,
+                                                          const g1x_xyzz_t* __restrict__ col, uint32_t m, uint32_t ml,
+                                                          g1_xyzz_t* __restrict__ out) {
+    __shared__ g1x_xyzz_t red[256];
+    const uint32_t rows = 1u << (m - ml), cols = 1u << ml;
+    const uint32_t q = blockIdx.x, nq = gridDim.x, w = blockIdx.y, tid = threadIdx.x;
+    const g1x_xyzz_t* src;
+    uint32_t count, bit = 0;
+    if (q == 0) {
+        src = arow + (size_t)w * rows; count = rows;
+    } else if (q - 1 < ml) {
+        src = col + (size_t)w * cols; count = cols >> 1; bit = q - 1;
+    } else {
+        src = row + (size_t)w * rows; count = rows >> 1; bit = q - 1 - ml;
+    }
+    // q > 0: the k-th index with bit `bit` set
+    const PtX acc = reduce_points<256>(src, count, [=](uint32_t k) -> size_t {
+        return q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
+    }, red, tid);
     if (tid != 0) return;
-    g1_xyzz_t r;
+    g1_xyzz_t r;   // back to the saturated form for the host
     r.x = x_to_sat<FqX>(acc.x); r.y = x_to_sat<FqX>(acc.y); r.zz = x_to_sat<FqX>(acc.zz); r.zzz = x_to_sat<FqX>(acc.zzz);
-    st_xyzz(out + item, r);
+    st_xyzz(out + (size_t)w * nq + q, r);
 }
 
 // saturated affine -> x-form affine
@@ -563,7 +611,7 @@ struct MsmSlot {
     uint32_t* host_entries = nullptr;   // pinned: (point, sign) entries of the last run
     DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, part_hist, order, bins;
     DevBuf<uint2> coarse;
-    DevBuf<g1x_xyzz_t> buckets, pieces, A, R, partial;
+    DevBuf<g1x_xyzz_t> buckets, pieces, A, R, row, arow, col;
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
     size_t host_cap = 0;
@@ -635,7 +683,6 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     uint32_t log_chunks = 0;
     while ((1u << log_chunks) < chunks) ++log_chunks;
     const uint32_t nq = 1 + log_chunks;
-    const uint32_t parts = std::min(64u, std::max(1u, chunks / (small_set ? 256u : 2048u)));
     s.c = c; s.W = S; s.nq = nq; s.log_chunks = log_chunks; s.chunk_log = chunk_log;
     // sort geometry: low_bits of the bucket id are sorted per coarse bin, the rest select the bin
     uint32_t kbits = 0;
@@ -668,7 +715,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     s.pieces.ensure((size_t)max_huge * HUGE_PIECES);
     s.A.ensure(total_chunks);
     s.R.ensure(total_chunks);
-    s.partial.ensure((size_t)S * nq * parts);
+    const uint32_t ml = (log_chunks + 1) / 2, rows = 1u << (log_chunks - ml), cols = 1u << ml;
+    s.row.ensure((size_t)S * rows);
+    s.arow.ensure((size_t)S * rows);
+    s.col.ensure((size_t)S * cols);
     s.sums.ensure((size_t)S * nq);
     if ((size_t)S * nq > s.host_cap) {
         if (s.host_sums) (void)hipHostFree(s.host_sums);
@@ -725,8 +775,9 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
     hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunk_log, chunks,
                        total_chunks, s.A.p, s.R.p);
-    hipLaunchKernelGGL(msm_tree_kernel, dim3(nq * parts, S), dim3(256), 0, st, s.A.p, s.R.p, chunks, parts, nq, s.partial.p);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(S * nq), dim3(64), 0, st, s.partial.p, parts, s.sums.p);
+    hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(64), 0, st, s.A.p, s.R.p, log_chunks, ml, s.row.p,
+                       s.arow.p, s.col.p);
+    hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(256), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, s.sums.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)S * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[4], st));
