@@ -146,9 +146,10 @@ __global__ __launch_bounds__(1024) void scan_middle_kernel(fr_t* totals, uint32_
     for (uint32_t k = lo; k < hi; ++k) st(totals + k, scan_op<OP>(excl, ld(totals + k)));
 }
 
+// x and out may be the same vector (no __restrict__: every element is read before it is written)
 template <int OP>
-__global__ __launch_bounds__(256) void scan_apply_kernel(const fr_t* __restrict__ x, uint32_t n, int reverse,
-                                                          const fr_t* __restrict__ totals, fr_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void scan_apply_kernel(const fr_t* x, uint32_t n, int reverse,
+                                                          const fr_t* __restrict__ totals, fr_t* out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lo = t * CH;
     if (lo >= n) return;
@@ -162,15 +163,29 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const fr_t* __restrict_
     }
 }
 
+// `totals` is scratch for the per-chunk totals of every level: m + m/CH + ... elements.
+template <int OP>
+static void exclusive_scan_level(Ctx* ctx, const fr_t* x, fr_t* out, uint32_t n, bool reverse, fr_t* totals) {
+    const uint32_t m = (n + CH - 1) / CH;
+    const uint32_t blocks = (m + 255) / 256;
+    hipLaunchKernelGGL(scan_totals_kernel<OP>, dim3(blocks), dim3(256), 0, ctx->stream, x, n, reverse ? 1 : 0, totals);
+    // the chunk totals are scanned in the same direction by the level above (in place); only a few
+    // thousand are left to the single-workgroup kernel, whose run time is a chain of dependent steps
+    if (m > 4096) exclusive_scan_level<OP>(ctx, totals, totals, m, false, totals + m);
+    else hipLaunchKernelGGL(scan_middle_kernel<OP>, dim3(1), dim3(1024), 0, ctx->stream, totals, m);
+    hipLaunchKernelGGL(scan_apply_kernel<OP>, dim3(blocks), dim3(256), 0, ctx->stream, x, n, reverse ? 1 : 0, totals, out);
+}
+
 template <int OP>
 static void exclusive_scan(Ctx* ctx, const fr_t* x, fr_t* out, uint32_t n, bool reverse, DevBuf<fr_t>& totals) {
     if (n == 0) return;
-    const uint32_t m = (n + CH - 1) / CH;
-    totals.ensure(m);
-    const uint32_t blocks = (m + 255) / 256;
-    hipLaunchKernelGGL(scan_totals_kernel<OP>, dim3(blocks), dim3(256), 0, ctx->stream, x, n, reverse ? 1 : 0, totals.p);
-    hipLaunchKernelGGL(scan_middle_kernel<OP>, dim3(1), dim3(1024), 0, ctx->stream, totals.p, m);
-    hipLaunchKernelGGL(scan_apply_kernel<OP>, dim3(blocks), dim3(256), 0, ctx->stream, x, n, reverse ? 1 : 0, totals.p, out);
+    size_t need = 0;
+    for (uint32_t m = (n + CH - 1) / CH;; m = (m + CH - 1) / CH) {
+        need += m;
+        if (m <= 4096) break;
+    }
+    totals.ensure(need);
+    exclusive_scan_level<OP>(ctx, x, out, n, reverse, totals.p);
     HIP_CHECK(hipGetLastError());
 }
 
