@@ -302,6 +302,21 @@ __global__ __launch_bounds__(256) void nonzero_kernel(const fr_t* __restrict__ x
     if (!f_is_zero<FrP>(ld(x + i))) atomicOr(flag, 2u);
 }
 
+// ---- device-to-device copy as a kernel: hipMemcpyAsync may route a same-device copy through a DMA
+//      engine at a few percent of the HBM rate (1.7 ms for 32 MB measured) ----
+__global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+void poly_copy(Ctx* ctx, fr_t* dst, const fr_t* src, size_t n) {
+    if (n == 0) return;
+    const size_t n16 = n * (sizeof(fr_t) / sizeof(uint4));
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n16 + 255) / 256, 8192);
+    hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst), n16);
+    HIP_CHECK(hipGetLastError());
+}
+
 void poly_blind(Ctx* ctx, fr_t* coeffs, uint32_t n, const host::fr_h* bl, uint32_t k) {
     BlindArgs b;
     b.k = k;

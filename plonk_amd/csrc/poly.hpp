@@ -33,6 +33,7 @@ struct LincombArgs {
 
 void poly_blind(Ctx* ctx, fr_t* coeffs, uint32_t n, const host::fr_h* bl, uint32_t k);
 void poly_poke(Ctx* ctx, fr_t* coeffs, uint32_t idx, const host::fr_h& v, bool subtract);
+void poly_copy(Ctx* ctx, fr_t* dst, const fr_t* src, size_t n);   // same-device copy by a kernel
 void perm_terms(Ctx* ctx, const PermArgs& p);
 void perm_ratio(Ctx* ctx, const fr_t* num, fr_t* den, uint32_t n, fr_t* scratch, uint32_t* flag);
 void scan_prefix_product(Ctx* ctx, const fr_t* x, fr_t* out, uint32_t n, DevBuf<fr_t>& totals);

@@ -310,18 +310,24 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     HIP_CHECK(hipMemsetAsync(ws->tp.p, 0, 3 * ns * sizeof(fr_t), st));
 
     // ---- round 1 (prover.rs:181-244) ----
+    // wire evaluations: a resident witness is read where it lies, a host witness is staged in ws->ev
     const plonk_fr* evs[3] = {a_ev, b_ev, c_ev};
+    const fr_t* EV[3];
     for (int k = 0; k < 3; ++k) {
-        HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t),
-                                 evals_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(W[k], ws->ev.p + k * n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+        if (evals_on_device) {
+            EV[k] = reinterpret_cast<const fr_t*>(evs[k]);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+            EV[k] = ws->ev.p + k * n;
+        }
+        poly_copy(ctx, W[k], EV[k], n);
     }
     ntt_run(ctx, W[0], log_n, NTT_INVERSE, 3, n4);
     host::G1AffineH comm[9];
     for (int k = 0; k < 3; ++k) {
         const fr_h b2[2] = {bl[2 * k + 1], bl[2 * k]};  // blind poly [b2, b1] (:205-207)
         poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
-        HIP_CHECK(hipMemcpyAsync(CO[k], W[k], (n + 2) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+        poly_copy(ctx, CO[k], W[k], n + 2);
     }
     {
         const fr_t* cp[3] = {CO[0], CO[1], CO[2]};
@@ -337,7 +343,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     // ---- round 2 (prover.rs:247-336) ----
     {
         PermArgs p;
-        p.a = ws->ev.p; p.b = ws->ev.p + n; p.c = ws->ev.p + 2 * n;
+        p.a = EV[0]; p.b = EV[1]; p.c = EV[2];
         p.s1 = pk->sig_ev.p; p.s2 = pk->sig_ev.p + n; p.s3 = pk->sig_ev.p + 2 * n;
         p.w_lo = pk->w_lo.p; p.w_hi = pk->w_hi.p;
         p.num = ws->num.p; p.den = ws->den.p;
@@ -352,7 +358,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     {
         const fr_h b3[3] = {bl[8], bl[7], bl[6]};  // [b9, b8, b7] (:319)
         poly_blind(ctx, W[3], (uint32_t)n, b3, 3);
-        HIP_CHECK(hipMemcpyAsync(CO[3], W[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+        poly_copy(ctx, CO[3], W[3], n + 3);
     }
     comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard);
     check_flag(ctx, ws);
@@ -373,9 +379,9 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
     ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
     poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
-    HIP_CHECK(hipMemcpyAsync(TP[0], ws->t.p, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(TP[1], ws->t.p + n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(TP[2], ws->t.p + 2 * n, std::min(n + 6, n4 - 2 * n) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    poly_copy(ctx, TP[0], ws->t.p, n);
+    poly_copy(ctx, TP[1], ws->t.p + n, n);
+    poly_copy(ctx, TP[2], ws->t.p + 2 * n, std::min(n + 6, n4 - 2 * n));
     poly_poke(ctx, TP[0], (uint32_t)n, bl[9], false);   // t_lo  += b10 X^n   (:540-543)
     poly_poke(ctx, TP[1], 0, bl[9], true);              // t_mid -= b10
     poly_poke(ctx, TP[1], (uint32_t)n, bl[10], false);  // t_mid += b11 X^n
@@ -470,7 +476,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
         // W_{zeta omega} = (z - z_bar_omega) / (X - zeta omega)  (:815-816)
-        HIP_CHECK(hipMemcpyAsync(ws->wnum.p, CO[3], (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+        poly_copy(ctx, ws->wnum.p, CO[3], n + 3);
         poly_poke(ctx, ws->wnum.p, 0, zw_bar, true);
         HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq2.p, ws->totals);
