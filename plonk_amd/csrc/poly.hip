@@ -23,24 +23,103 @@ __device__ __forceinline__ fr_t fr_pow_u64(fr_t b, uint64_t e) {
     return r;
 }
 
-// a^(r-2)
-__device__ __noinline__ fr_t fr_inverse(const fr_t& a) {
-    fr_t r = f_one<FrP>();
-#pragma unroll 1
-    for (int limb = 7; limb >= 0; --limb) {
-        uint32_t e;  // limb of r - 2 (r = ...ffffffff_00000001, so r - 2 = ...fffffffe_ffffffff)
-        switch (limb) {
-            case 7: e = FrP::p(7); break; case 6: e = FrP::p(6); break; case 5: e = FrP::p(5); break;
-            case 4: e = FrP::p(4); break; case 3: e = FrP::p(3); break; case 2: e = FrP::p(2); break;
-            case 1: e = 0xfffffffeu; break; default: e = 0xffffffffu; break;
-        }
-#pragma unroll 1
-        for (int bit = 31; bit >= 0; --bit) {
-            r = fr_mul(r, r);
-            if ((e >> bit) & 1u) r = fr_mul(r, a);
-        }
+// ---- inversion of a nonzero Montgomery residue by the binary "almost inverse" (Kaliski): the loop
+//      below ends with r = -a^-1 2^k mod p, 255 <= k <= 510, after k rounds of shifts, one 256-bit
+//      subtraction and one addition each -- about a fifth of the dependent instructions of the
+//      exponentiation a^(p-2), which matters because one lane's inversion is the longest chain of
+//      the round-2 kernel.  With a = x R the wanted x^-1 R is (p - r) * 2^(512 - k). ----
+struct U256 {
+    uint32_t l[8];
+};
+__device__ __forceinline__ U256 u256_shr1(const U256& a) {
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) r.l[i] = (a.l[i] >> 1) | (a.l[i + 1] << 31);
+    r.l[7] = a.l[7] >> 1;
+    return r;
+}
+__device__ __forceinline__ U256 u256_shl1(const U256& a) {
+    U256 r;
+    r.l[0] = a.l[0] << 1;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.l[i] = (a.l[i] << 1) | (a.l[i - 1] >> 31);
+    return r;
+}
+__device__ __forceinline__ U256 u256_add(const U256& a, const U256& b) {
+    U256 r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
     }
     return r;
+}
+// a - b and whether it borrowed (a < b)
+__device__ __forceinline__ U256 u256_sub(const U256& a, const U256& b, bool& borrow) {
+    U256 r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += (int64_t)a.l[i] - (int64_t)b.l[i];
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    borrow = c != 0;
+    return r;
+}
+__device__ __forceinline__ U256 u256_sel(bool take_a, const U256& a, const U256& b) {
+    U256 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.l[i] = take_a ? a.l[i] : b.l[i];
+    return r;
+}
+
+__device__ __noinline__ fr_t fr_inverse(const fr_t& a) {
+    U256 u, v, r, s, pm;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        pm.l[i] = FrP::p(i);
+        u.l[i] = pm.l[i];
+        v.l[i] = a.l[i];
+        r.l[i] = 0;
+        s.l[i] = i == 0 ? 1u : 0u;
+    }
+    uint32_t k = 0;
+#pragma unroll 1
+    for (;;) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) any |= v.l[i];
+        if (any == 0 || k >= 512u) break;   // k <= 510 for any nonzero residue below p; the cap bounds the loop on other input
+        const bool u_even = (u.l[0] & 1u) == 0, v_even = (v.l[0] & 1u) == 0;
+        bool u_lt_v, v_lt_u;
+        const U256 umv = u256_sub(u, v, u_lt_v);
+        const U256 vmu = u256_sub(v, u, v_lt_u);
+        const bool case_a = u_even, case_b = !u_even && v_even;
+        const bool case_c = !u_even && !v_even && v_lt_u;    // u > v
+        const bool case_d = !u_even && !v_even && !v_lt_u;   // u <= v (equal only at u = v = 1: v becomes 0)
+        const U256 t = u256_add(r, s);
+        u = case_a ? u256_shr1(u) : (case_c ? u256_shr1(umv) : u);
+        v = case_b ? u256_shr1(v) : (case_d ? u256_shr1(vmu) : v);
+        if (case_c) r = t;
+        if (case_d) s = t;
+        if (case_a || case_c) s = u256_shl1(s);
+        else r = u256_shl1(r);
+        ++k;
+    }
+    bool lt;
+    const U256 r_red = u256_sub(r, pm, lt);
+    r = u256_sel(lt, r, r_red);                 // r mod p
+    const U256 res = u256_sub(pm, r, lt);       // p - r = a^-1 2^k mod p
+    // times 2^(512 - k): as a Montgomery product with the Montgomery form of that power of two
+    fr_t pow2 = f_one<FrP>(), out;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 512u - k; ++i) pow2 = fr_add(pow2, pow2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.l[i] = res.l[i];
+    return fr_mul(out, pow2);
 }
 
 // coeffs[j] -= bl[j], coeffs[n + j] += bl[j], j < k:  adds (bl[k-1] X^(k-1) + ... + bl[0]) * (X^n - 1)
@@ -76,24 +155,53 @@ __global__ __launch_bounds__(256) void perm_terms_kernel(PermArgs p) {
     st(p.den + i, den);
 }
 
-// x[i] <- num[i] / x[i] per chunk of CH (Montgomery's trick).  A zero denominator sets *flag
-// (prover.rs:290 panics "Denominator is zero").
+// den[i] <- num[i] / den[i] by Montgomery's trick over a whole workgroup: every lane multiplies up its
+// RATIO_CH consecutive denominators, the 256 lane products are scanned in LDS from both sides, ONE
+// lane inverts the workgroup's product (a 255-bit exponentiation: the longest dependent chain of the
+// kernel, so it is paid once per 256 lanes, not once per lane), and every lane unwinds its chunk.
+// A zero denominator sets *flag (prover.rs:290 panics "Denominator is zero").
+static constexpr uint32_t RATIO_CH = 16;
+
 __global__ __launch_bounds__(256) void ratio_kernel(const fr_t* __restrict__ num, fr_t* __restrict__ den, uint32_t n,
                                                      fr_t* __restrict__ scratch, uint32_t* __restrict__ flag) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lo = t * CH;
-    if (lo >= n) return;
-    const uint32_t hi = min(n, lo + CH);
+    __shared__ fr_t pre[256];   // inclusive prefix products of the lane products
+    __shared__ fr_t suf[256];   // inclusive suffix products
+    __shared__ fr_t inv_all;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lo = min(n, (blockIdx.x * 256 + tid) * RATIO_CH), hi = min(n, lo + RATIO_CH);
     fr_t run = f_one<FrP>();
+    bool zero = false;
     for (uint32_t i = lo; i < hi; ++i) {
-        st(scratch + i, run);
-        const fr_t d = ld(den + i);
-        if (f_is_zero<FrP>(d)) { atomicOr(flag, 1u); return; }
+        st(scratch + i, run);   // product of this lane's denominators before i
+        fr_t d = ld(den + i);
+        if (f_is_zero<FrP>(d)) { zero = true; d = f_one<FrP>(); }
         run = fr_mul(run, d);
     }
-    fr_t inv = fr_inverse(run);
+    if (zero) atomicOr(flag, 1u);
+    st(&pre[tid], run);
+    st(&suf[tid], run);
+    __syncthreads();
+    fr_t p = run, q = run;
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        fr_t pv = f_one<FrP>(), qv = f_one<FrP>();
+        if (tid >= off) pv = ld(&pre[tid - off]);
+        if (tid + off < 256) qv = ld(&suf[tid + off]);
+        __syncthreads();
+        p = fr_mul(pv, p);
+        q = fr_mul(q, qv);
+        st(&pre[tid], p);
+        st(&suf[tid], q);
+        __syncthreads();
+    }
+    if (tid == 0) st(&inv_all, fr_inverse(ld(&pre[255])));
+    __syncthreads();
+    // 1 / (this lane's product) = 1 / (all) * (lanes before) * (lanes after)
+    fr_t inv = ld(&inv_all);
+    if (tid > 0) inv = fr_mul(inv, ld(&pre[tid - 1]));
+    if (tid < 255) inv = fr_mul(inv, ld(&suf[tid + 1]));
     for (uint32_t i = hi; i-- > lo;) {
-        const fr_t d = ld(den + i);
+        fr_t d = ld(den + i);
+        if (f_is_zero<FrP>(d)) d = f_one<FrP>();
         const fr_t dinv = fr_mul(inv, ld(scratch + i));
         inv = fr_mul(inv, d);
         st(den + i, fr_mul(ld(num + i), dinv));
@@ -336,7 +444,7 @@ void perm_terms(Ctx* ctx, const PermArgs& p) {
 }
 
 void perm_ratio(Ctx* ctx, const fr_t* num, fr_t* den, uint32_t n, fr_t* scratch, uint32_t* flag) {
-    const uint32_t lanes = (n + CH - 1) / CH;
+    const uint32_t lanes = (n + RATIO_CH - 1) / RATIO_CH;
     hipLaunchKernelGGL(ratio_kernel, dim3((lanes + 255) / 256), dim3(256), 0, ctx->stream, num, den, n, scratch, flag);
     HIP_CHECK(hipGetLastError());
 }
