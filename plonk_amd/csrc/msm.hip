@@ -365,6 +365,42 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
     st_ptx(buckets + gid, acc);
 }
 
+// ---- 5a'. the same for a small bucket set: with fewer buckets than the chip has lanes, 2^LOG_LPB
+//          neighbouring lanes share a bucket (entries k = sub, sub + LPB, ...) and fold their sums
+//          through LDS, so the dependent chain of additions per lane is LPB times shorter ----
+template <uint32_t LOG_LPB>
+__global__ __launch_bounds__(256) void msm_bucket_split_kernel(const g1x_affine_t* __restrict__ points,
+                                                                const uint32_t* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ offsets,
+                                                                const uint32_t* __restrict__ counts,
+                                                                uint32_t total_buckets, const uint32_t* __restrict__ order,
+                                                                const uint32_t* __restrict__ n_big,
+                                                                g1x_xyzz_t* __restrict__ buckets) {
+    constexpr uint32_t LPB = 1u << LOG_LPB;
+    __shared__ g1x_xyzz_t red[256];
+    const uint32_t tid = threadIdx.x, sub = tid & (LPB - 1);
+    const uint32_t slot = ((blockIdx.x * 256 + tid) >> LOG_LPB) + n_big[0];
+    const bool live = slot < total_buckets;
+    const uint32_t gid = live ? order[slot] : 0u;
+    const uint32_t cnt = live ? counts[gid] : 0u;
+    const uint32_t* src = sorted + (live ? offsets[gid] : 0u);
+    PtX acc = ptx_identity();
+    for (uint32_t k = sub; k < cnt; k += LPB) {
+        const AffX p = load_signed_point(points, src[k]);
+        ptx_madd(acc, p);
+    }
+#pragma unroll 1
+    for (uint32_t half = LPB >> 1; half > 0; half >>= 1) {
+        st_ptx(&red[tid], acc);
+        __syncthreads();
+        PtX o = ptx_identity();
+        if (sub < half) o = ld_ptx(&red[tid + half]);
+        __syncthreads();
+        ptx_add<MulInline>(acc, o);
+    }
+    if (live && sub == 0) st_ptx(buckets + gid, acc);
+}
+
 // sum over the workgroup of the lanes' points, result in lane 0's acc
 __device__ __forceinline__ void block_sum_256(PtX& acc, g1x_xyzz_t* red, uint32_t tid) {
     st_ptx(&red[tid], acc);
@@ -764,8 +800,22 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
                        s.order.p, n_big, max_huge, s.pieces.p, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[2], st));
-    hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                       total_buckets, s.order.p, n_big, s.buckets.p);
+    // lanes per bucket: a small bucket set with long buckets is spread over more lanes
+    uint32_t log_lpb = 0;
+    while (log_lpb < 3 && (total_buckets << log_lpb) < (1u << 17) && (mean >> log_lpb) >= 16) ++log_lpb;
+    const uint32_t sblk = (uint32_t)((((size_t)total_buckets << log_lpb) + 255) / 256);
+    if (log_lpb == 0)
+        hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
+                           total_buckets, s.order.p, n_big, s.buckets.p);
+    else if (log_lpb == 1)
+        hipLaunchKernelGGL(msm_bucket_split_kernel<1>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+    else if (log_lpb == 2)
+        hipLaunchKernelGGL(msm_bucket_split_kernel<2>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+    else
+        hipLaunchKernelGGL(msm_bucket_split_kernel<3>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[3], st));
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
     return;
@@ -910,7 +960,7 @@ uint32_t msm_table_bits(size_t n) {
     // window would only add buckets; larger inputs put more points into each of the 2^19 buckets.
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    return lg <= 16 ? 16u : 20u;
+    return lg <= 17 ? 16u : 20u;
 }
 
 // Builds srs->px as the window table [W][n]: row w holds 2^(c w) P_i in x-form.  With the table
