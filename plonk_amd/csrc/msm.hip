@@ -701,7 +701,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
                         bool tail_phase) {
     const g1x_affine_t* points = pts.px;
     // the table pays once the shared bucket set (2^(table_c-1) buckets) is reasonably full
-    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 4)) != 0) ? 1u : 0u;
+    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 6)) != 0) ? 1u : 0u;
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
     if (n == 0) return;
