@@ -12,7 +12,7 @@
 //   4. reduce   : sum_b b * B_b: lanes take chunks of L buckets (running sums A_t, R_t), then
 //                 sum A_t and the bit-masked sums of R_t by LDS trees (sum_t t R_t = sum_i 2^i G_i).
 //   5. the few resulting points are combined and normalised on the host: O(100) point operations.
-// An SRS of >= 2^14 points carries a table of its points times 2^(c w): all windows then share ONE
+// An SRS of >= 2^10 points carries a table of its points times 2^(c w): all windows then share ONE
 // bucket set, so steps 3-4 run over 2^(c-1) buckets once instead of once per window.
 // Integer VALU work throughout; bytes moved are negligible next to the field multiplications.
 #include <algorithm>
