@@ -258,6 +258,31 @@ __device__ __forceinline__ Limbs<X::N32> x_to_sat(const xe_t<X>& x) {  // x belo
     return x_repack_out<X>(x_canon2<X>(x_mul<X>(x, k)));
 }
 
+// ---- Fr in this form: register type, a 48-byte table slot (9 limbs + 3 pad words), and the host-side
+//      conversion of a saturated Montgomery value (radix 2^256) into a true value of this form
+//      (radix 2^261: the value times 2^5, regrouped into 29-bit limbs) ----
+typedef xe_t<FrX> frx;
+struct alignas(16) frx_slot {
+    uint32_t w[12];
+};
+__device__ __forceinline__ frx ld_tw(const frx_slot* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    frx r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x;
+    return r;
+}
+// `mont_times_32`: the four 64-bit words of (Montgomery value * 32 mod p)
+inline void frx_words_from_u64(const uint64_t mont_times_32[4], uint32_t out[9]) {
+    for (int k = 0; k < 9; ++k) {
+        const int bit = k * 29, limb = bit / 64, off = bit % 64;
+        uint64_t w = mont_times_32[limb] >> off;
+        if (off > 64 - 29 && limb + 1 < 4) w |= mont_times_32[limb + 1] << (64 - off);
+        out[k] = (uint32_t)w & ((1u << 29) - 1u);
+    }
+}
+
 // 64-byte storage slot for an Fq x-form element (14 limbs + 2 pad words)
 struct alignas(16) fqx_slot {
     uint32_t w[16];

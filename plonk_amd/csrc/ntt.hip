@@ -33,19 +33,6 @@ static constexpr int NTT_THREADS = 256;
 // that way is the element times 2^-5, and the outputs carry the same factor back); only the
 // twiddle tables are true x-form values.  Elements in LDS and in the intermediate image stay
 // below 2p.
-typedef xe_t<FrX> frx;
-struct alignas(16) frx_slot {
-    uint32_t w[12];  // 9 limbs + 3 pad words
-};
-__device__ __forceinline__ frx ld_tw(const frx_slot* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    const uint4 a = q[0], b = q[1], c = q[2];
-    frx r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x;
-    return r;
-}
-
 struct NttPassArgs {
     const fr_t* in;
     fr_t* out;
@@ -288,12 +275,7 @@ static void upload(DevBuf<frx_slot>& buf, const std::vector<host::fr_h>& v) {
     for (size_t i = 0; i < v.size(); ++i) {
         const host::fr_h t = host::Fr::mul(v[i], k32);
         memset(&x[i], 0, sizeof(frx_slot));
-        for (int k = 0; k < 9; ++k) {
-            const int bit = k * 29, limb = bit / 64, off = bit % 64;
-            uint64_t w = t.l[limb] >> off;
-            if (off > 64 - 29 && limb + 1 < 4) w |= t.l[limb + 1] << (64 - off);
-            x[i].w[k] = (uint32_t)w & ((1u << 29) - 1u);
-        }
+        frx_words_from_u64(t.l, x[i].w);
     }
     buf.alloc(x.size());
     if (!x.empty()) HIP_CHECK(hipMemcpy(buf.p, x.data(), x.size() * sizeof(frx_slot), hipMemcpyHostToDevice));

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fieldx.cuh"
 #include "msm.hpp"
 #include "poly.hpp"
 #include "prover.hpp"
@@ -19,45 +20,71 @@ using host::Fr;
 using host::fr_h;
 
 // ---- fused quotient evaluation over the 4n coset points (prover.rs:415-457) ----
+// Arithmetic in the 29-bit-limb form of fieldx.cuh.  Vectors stay saturated Montgomery words in
+// memory; regrouped into 29-bit limbs a word image reads as the value divided by 32 ("scaled").
+// Sums of scaled values are scaled values; a product of two scaled values comes out 32 times too
+// small; a product with a constant held as a true value of the form keeps the scale.  Every term
+// below is arranged to end up scaled exactly once, so the result regroups back into the saturated
+// word image of t: q_M is stored times 2^10 and q_L, q_R, q_O times 2^5 in the key's coset tables,
+// and the challenges that multiply the permutation and L1 terms carry 2^15 and 2^5.
 struct QuotientArgs {
     const fr_t *a, *b, *c, *z, *pi;   // coset evaluations, 4n each (pi nullable)
-    const fr_t* pk_ext;               // [9][4n]: q_m q_l q_r q_o q_c s1 s2 s3 l1
-    const fr_t *x_lo, *x_hi;          // x_i = x_lo[i & mask] * x_hi[i >> log_l] = 7 * w_4n^i
+    const fr_t* pk_ext;               // [9][4n]: 2^10 q_m, 2^5 q_l, 2^5 q_r, 2^5 q_o, q_c, s1, s2, s3, l1
+    const fr_t* x_lo;                 // x_i = x_lo[i & mask] * x_hi[i >> log_l] = 7 * w_4n^i
+    const frx_slot* x_hi;             //   (x_hi as true values)
     fr_t* t;
-    fr_t alpha, alpha2, beta, gamma, beta_k1, beta_k2;
-    fr_t zh_inv[4];                   // 1 / (x_i^n - 1) depends on i mod 4 only
+    frx alpha_32_3, alpha2_32, beta, beta_k1, beta_k2;   // true values: 2^15 alpha, 2^5 alpha^2, beta, beta k1, beta k2
+    frx zh_inv[4];                    // true values; 1 / (x_i^n - 1) depends on i mod 4 only
+    fr_t gamma, one;                  // saturated words (read as scaled values)
     uint32_t n4, log_l;
 };
+
+__device__ __forceinline__ frx ld_scaled(const fr_t* p) { return x_repack_in<FrX>(ld(p)); }
 
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientArgs q) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.n4) return;
     const size_t N = q.n4;
-    const fr_t a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), z = ld(q.z + i);
-    const fr_t zw = ld(q.z + ((i + 4) & (q.n4 - 1)));  // z(w X) on the 4n coset is a rotation by 4
-    fr_t x = ld(q.x_lo + (i & ((1u << q.log_l) - 1u)));
-    if (i >> q.log_l) x = fr_mul(x, ld(q.x_hi + (i >> q.log_l)));
-    // gate: q_M a b + q_L a + q_R b + q_O c + q_C + PI
-    fr_t gate = fr_mul(fr_mul(ld(q.pk_ext + i), a), b);
-    gate = fr_add(gate, fr_mul(ld(q.pk_ext + N + i), a));
-    gate = fr_add(gate, fr_mul(ld(q.pk_ext + 2 * N + i), b));
-    gate = fr_add(gate, fr_mul(ld(q.pk_ext + 3 * N + i), c));
-    gate = fr_add(gate, ld(q.pk_ext + 4 * N + i));
-    if (q.pi) gate = fr_add(gate, ld(q.pi + i));
-    // permutation
-    const fr_t ag = fr_add(a, q.gamma), bg = fr_add(b, q.gamma), cg = fr_add(c, q.gamma);
-    fr_t num = fr_mul(z, fr_add(ag, fr_mul(q.beta, x)));
-    num = fr_mul(num, fr_add(bg, fr_mul(q.beta_k1, x)));
-    num = fr_mul(num, fr_add(cg, fr_mul(q.beta_k2, x)));
-    fr_t den = fr_mul(zw, fr_add(ag, fr_mul(q.beta, ld(q.pk_ext + 5 * N + i))));
-    den = fr_mul(den, fr_add(bg, fr_mul(q.beta, ld(q.pk_ext + 6 * N + i))));
-    den = fr_mul(den, fr_add(cg, fr_mul(q.beta, ld(q.pk_ext + 7 * N + i))));
-    const fr_t perm = fr_sub(num, den);
-    const fr_t l1c = fr_mul(ld(q.pk_ext + 8 * N + i), fr_sub(z, f_one<FrP>()));
-    fr_t numer = fr_add(gate, fr_add(fr_mul(q.alpha, perm), fr_mul(q.alpha2, l1c)));
+    const frx a = ld_scaled(q.a + i), b = ld_scaled(q.b + i), c = ld_scaled(q.c + i), z = ld_scaled(q.z + i);
+    const frx zw = ld_scaled(q.z + ((i + 4) & (q.n4 - 1)));  // z(w X) on the 4n coset is a rotation by 4
+    frx x = ld_scaled(q.x_lo + (i & ((1u << q.log_l) - 1u)));
+    if (i >> q.log_l) x = x_mul<FrX>(x, ld_tw(q.x_hi + (i >> q.log_l)));
+    // gate: q_M a b + q_L a + q_R b + q_O c + q_C + PI   (each product below 2p, limbs normalised)
+    frx gate = x_mul<FrX>(x_mul<FrX>(ld_scaled(q.pk_ext + i), a), b);
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + N + i), a));
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 2 * N + i), b));
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 3 * N + i), c));
+    gate = x_add_lazy<FrX>(gate, ld_scaled(q.pk_ext + 4 * N + i));
+    if (q.pi) gate = x_add_lazy<FrX>(gate, ld_scaled(q.pi + i));
+    // permutation: the three-term factors are sums of at most 4p with limbs below 2^31
+    const frx gamma = x_repack_in<FrX>(q.gamma);
+    const frx ag = x_add_lazy<FrX>(a, gamma), bg = x_add_lazy<FrX>(b, gamma), cg = x_add_lazy<FrX>(c, gamma);
+    frx num = x_mul<FrX>(z, x_add_lazy<FrX>(ag, x_mul<FrX>(x, q.beta)));
+    num = x_mul<FrX>(num, x_add_lazy<FrX>(bg, x_mul<FrX>(x, q.beta_k1)));
+    num = x_mul<FrX>(num, x_add_lazy<FrX>(cg, x_mul<FrX>(x, q.beta_k2)));
+    frx den = x_mul<FrX>(zw, x_add_lazy<FrX>(ag, x_mul<FrX>(ld_scaled(q.pk_ext + 5 * N + i), q.beta)));
+    den = x_mul<FrX>(den, x_add_lazy<FrX>(bg, x_mul<FrX>(ld_scaled(q.pk_ext + 6 * N + i), q.beta)));
+    den = x_mul<FrX>(den, x_add_lazy<FrX>(cg, x_mul<FrX>(ld_scaled(q.pk_ext + 7 * N + i), q.beta)));
+    const frx perm = x_mul<FrX>(x_sub_lazy<FrX, 3>(num, den), q.alpha_32_3);     // three products deep: 2^-15
+    const frx zm1 = x_sub_lazy<FrX, 3>(z, x_repack_in<FrX>(q.one));
+    const frx l1c = x_mul<FrX>(x_mul<FrX>(zm1, ld_scaled(q.pk_ext + 8 * N + i)), q.alpha2_32);
+    const frx numer = x_norm_u<FrX>(x_add_lazy<FrX>(gate, x_add_lazy<FrX>(perm, l1c)));   // 8 terms: limbs below 2^32
     const uint32_t r = i & 3u;
-    const fr_t zi = r == 0 ? q.zh_inv[0] : (r == 1 ? q.zh_inv[1] : (r == 2 ? q.zh_inv[2] : q.zh_inv[3]));
-    st(q.t + i, fr_mul(numer, zi));
+    const frx zi = r == 0 ? q.zh_inv[0] : (r == 1 ? q.zh_inv[1] : (r == 2 ? q.zh_inv[2] : q.zh_inv[3]));
+    st(q.t + i, x_repack_out<FrX>(x_canon2<FrX>(x_mul<FrX>(numer, zi))));
+}
+
+// rows of the coset table times a constant (the 2^10 / 2^5 of q_M / q_L, q_R, q_O)
+__global__ __launch_bounds__(256) void scale_rows_kernel(fr_t* __restrict__ x, size_t count, fr_t k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st(x + i, fr_mul(ld(x + i), k));
+}
+
+static frx to_frx(const fr_h& mont) {
+    const fr_h t = Fr::mul(mont, Fr::from_u64(32));
+    frx r;
+    frx_words_from_u64(t.l, r.l);
+    return r;
 }
 
 static std::vector<fr_h> host_powers(const fr_h& first, const fr_h& base, size_t count) {
@@ -112,6 +139,12 @@ Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plon
     HIP_CHECK(hipMemcpy2DAsync(pk->ext.p, n4 * sizeof(fr_t), pk->coef.p, n * sizeof(fr_t), n * sizeof(fr_t), 9,
                                hipMemcpyDeviceToDevice, st));
     ntt_run(ctx, pk->ext.p, log_n + 2, NTT_COSET, 9, n4);
+    // the quotient kernel's scaling of the selector rows (see QuotientArgs)
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, st, pk->ext.p, n4,
+                       to_dev(Fr::from_u64(1024)));
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((uint32_t)((3 * n4 + 255) / 256)), dim3(256), 0, st, pk->ext.p + n4, 3 * n4,
+                       to_dev(Fr::from_u64(32)));
+    HIP_CHECK(hipGetLastError());
     // two-level tables: w^i (domain n) and x_i = 7 w_4n^i
     pk->log_lw = (log_n + 1) / 2;
     upload_fr(pk->w_lo, host_powers(Fr::one(), pk->omega, (size_t)1 << pk->log_lw));
@@ -121,8 +154,18 @@ Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plon
     const fr_h g = Fr::from_u64(7);
     pk->log_lx = (log_n + 3) / 2;
     upload_fr(pk->x_lo, host_powers(g, w4, (size_t)1 << pk->log_lx));
-    upload_fr(pk->x_hi, host_powers(Fr::one(), Fr::pow_u64(w4, (uint64_t)1 << pk->log_lx),
-                                    (size_t)1 << (log_n + 2 - pk->log_lx)));
+    {
+        const std::vector<fr_h> hi = host_powers(Fr::one(), Fr::pow_u64(w4, (uint64_t)1 << pk->log_lx),
+                                                 (size_t)1 << (log_n + 2 - pk->log_lx));
+        std::vector<frx_slot> slots(hi.size());
+        for (size_t i = 0; i < hi.size(); ++i) {
+            memset(&slots[i], 0, sizeof(frx_slot));
+            const frx v = to_frx(hi[i]);
+            memcpy(slots[i].w, v.l, sizeof(v.l));
+        }
+        pk->x_hi.alloc(slots.size());
+        HIP_CHECK(hipMemcpy(pk->x_hi.p, slots.data(), slots.size() * sizeof(frx_slot), hipMemcpyHostToDevice));
+    }
     // Z_H(7 w_4n^i) = 7^n * w_4^(i mod 4) - 1   (prover.rs:400-405)
     const fr_h gn = Fr::pow_u64(g, n);
     const fr_h i4 = Fr::pow_u64(w4, n);  // primitive 4th root of unity
@@ -145,13 +188,14 @@ void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr
     q.pk_ext = pk->ext.p;
     q.x_lo = pk->x_lo.p; q.x_hi = pk->x_hi.p;
     q.t = t_out;
-    q.alpha = to_dev(alpha);
-    q.alpha2 = to_dev(Fr::mul(alpha, alpha));
-    q.beta = to_dev(beta);
+    q.alpha_32_3 = to_frx(Fr::mul(alpha, Fr::from_u64(32768)));
+    q.alpha2_32 = to_frx(Fr::mul(Fr::mul(alpha, alpha), Fr::from_u64(32)));
+    q.beta = to_frx(beta);
+    q.beta_k1 = to_frx(Fr::mul(beta, pk->k1));
+    q.beta_k2 = to_frx(Fr::mul(beta, pk->k2));
     q.gamma = to_dev(gamma);
-    q.beta_k1 = to_dev(Fr::mul(beta, pk->k1));
-    q.beta_k2 = to_dev(Fr::mul(beta, pk->k2));
-    for (int r = 0; r < 4; ++r) q.zh_inv[r] = to_dev(pk->zh_inv[r]);
+    q.one = to_dev(Fr::one());
+    for (int r = 0; r < 4; ++r) q.zh_inv[r] = to_frx(pk->zh_inv[r]);
     q.n4 = n4;
     q.log_l = pk->log_lx;
     hipLaunchKernelGGL(quotient_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, q);

@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fieldx.cuh"
 #include "msm.hpp"
 
 namespace plonk {
@@ -15,9 +16,10 @@ struct Pk {
     host::fr_h k1, k2, omega;
     std::vector<uint32_t> pi_positions;
     DevBuf<fr_t> coef;    // [9][n]  coefficients: q_m q_l q_r q_o q_c s1 s2 s3 l1
-    DevBuf<fr_t> ext;     // [9][4n] evaluations on the coset 7*H_4n
+    DevBuf<fr_t> ext;     // [9][4n] evaluations on the coset 7*H_4n; rows q_m / q_l q_r q_o times 2^10 / 2^5
     DevBuf<fr_t> sig_ev;  // [3][n]  S_sigma evaluations on H
-    DevBuf<fr_t> w_lo, w_hi, x_lo, x_hi;
+    DevBuf<fr_t> w_lo, w_hi, x_lo;
+    DevBuf<frx_slot> x_hi;   // true values of the 29-bit-limb form (quotient kernel)
     uint32_t log_lw = 0, log_lx = 0;
     host::fr_h zh_inv[4];
 };
