@@ -75,6 +75,40 @@ __device__ __forceinline__ xe_t<X> x_mul(const xe_t<X>& a, const xe_t<X>& b) {
     return r;
 }
 
+// (a b + c d)/R' mod p under ONE reduction (a sum of two products costs 3/4 of two x_mul):
+// a, b, c normalised, d with limbs below 2^30 (an x_neg_lazy); result < (a b + c d)/R' + p, normalised.
+// A column holds at most L (2^58 + 2^59) of products and L 2^58 of reduction terms: < 2^64 for L <= 14.
+template <class X>
+__device__ __forceinline__ xe_t<X> x_mul2(const xe_t<X>& a, const xe_t<X>& b, const xe_t<X>& c2, const xe_t<X>& d) {
+    constexpr int L = X::L;
+    uint64_t c[2 * L];
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int j = 0; j < L; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int j = 0; j < L; ++j) c[i + j] += (uint64_t)c2.l[i] * d.l[j];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint32_t m = ((uint32_t)c[i] * X::INV) & XMASK;
+#pragma unroll
+        for (int j = 0; j < L; ++j) c[i + j] += (uint64_t)m * X::p(j);
+        c[i + 1] += c[i] >> 29;
+    }
+    xe_t<X> r;
+#pragma unroll
+    for (int k = 0; k < L - 1; ++k) {
+        r.l[k] = (uint32_t)c[L + k] & XMASK;
+        c[L + k + 1] += c[L + k] >> 29;
+    }
+    r.l[L - 1] = (uint32_t)c[2 * L - 1];
+    return r;
+}
+
 // a^2/R': the cross products are taken once against the doubled operand.
 template <class X>
 __device__ __forceinline__ xe_t<X> x_sqr(const xe_t<X>& a) {
@@ -131,15 +165,26 @@ __device__ __forceinline__ xe_t<X> x_add(const xe_t<X>& a, const xe_t<X>& b) {
     return x_norm<X>(t);
 }
 
-// a - b + M p with M in {2, 4, 8, 32}: the caller picks M >= the bound of b in units of p.
+// limb k of M p, M in {2, 4, 6, 8, 32}
+template <class X, int M>
+__device__ __forceinline__ constexpr uint32_t x_mp(int k) {
+    return M == 2 ? X::p2(k) : (M == 4 ? X::p4(k) : (M == 6 ? X::p6(k) : (M == 8 ? X::p8(k) : X::p32(k))));
+}
+
+// a - b + M p: the caller picks M >= the bound of b in units of p.
 template <class X, int M>
 __device__ __forceinline__ xe_t<X> x_sub(const xe_t<X>& a, const xe_t<X>& b) {
     xe_t<X> t;
 #pragma unroll
-    for (int k = 0; k < X::L; ++k) {
-        const uint32_t m = M == 2 ? X::p2(k) : (M == 4 ? X::p4(k) : (M == 8 ? X::p8(k) : X::p32(k)));
-        t.l[k] = a.l[k] - b.l[k] + m;
-    }
+    for (int k = 0; k < X::L; ++k) t.l[k] = a.l[k] - b.l[k] + x_mp<X, M>(k);
+    return x_norm<X>(t);
+}
+// a - b - 2c + M p under one normalisation: M >= the bound of b + 2c in units of p.
+template <class X, int M>
+__device__ __forceinline__ xe_t<X> x_sub_sub2(const xe_t<X>& a, const xe_t<X>& b, const xe_t<X>& c) {
+    xe_t<X> t;
+#pragma unroll
+    for (int k = 0; k < X::L; ++k) t.l[k] = a.l[k] - b.l[k] - (c.l[k] << 1) + x_mp<X, M>(k);
     return x_norm<X>(t);
 }
 
@@ -171,6 +216,15 @@ __device__ __forceinline__ xe_t<X> x_sub_lazy(const xe_t<X>& a, const xe_t<X>& b
     xe_t<X> t;
 #pragma unroll
     for (int k = 0; k < X::L; ++k) t.l[k] = a.l[k] + ((M == 3 ? X::bp3(k) : X::bp5(k)) - b.l[k]);
+    return t;
+}
+
+// M p - b without carries (limbs below 2^30), M in {3, 5}: b normalised and below (M - 1) p
+template <class X, int M>
+__device__ __forceinline__ xe_t<X> x_neg_lazy(const xe_t<X>& b) {
+    xe_t<X> t;
+#pragma unroll
+    for (int k = 0; k < X::L; ++k) t.l[k] = (M == 3 ? X::bp3(k) : X::bp5(k)) - b.l[k];
     return t;
 }
 

@@ -24,36 +24,14 @@ struct PtX {
 __device__ __forceinline__ fqx qmul(const fqx& a, const fqx& b) { return x_mul<FqX>(a, b); }
 __device__ __forceinline__ fqx qsqr(const fqx& a) { return x_sqr<FqX>(a); }
 
-// How a point operation multiplies.  MulInline expands every product in place: ~3.5 KB of code per
-// product, right for the bucket loop whose many waves share one instruction stream.  MulCall goes
-// through one out-of-line routine (operands and result in registers), so a whole point addition
-// stays a few KB: the reductions after the bucket phase run a handful of waves through long
-// dependent chains, and there instruction fetch of the expanded form costs more than the
-// arithmetic.
+// How a point operation multiplies: every product expanded in place (~3.5 KB of code each).
 struct MulInline {
     static __device__ __forceinline__ fqx mul(const fqx& a, const fqx& b) { return x_mul<FqX>(a, b); }
     static __device__ __forceinline__ fqx sqr(const fqx& a) { return x_sqr<FqX>(a); }
-};
-struct MulCall {
-    // operands as 14-lane vectors: those travel in registers, a struct argument would go through
-    // scratch memory
-    typedef uint32_t vec __attribute__((ext_vector_type(14)));
-    static __device__ __forceinline__ vec pack(const fqx& a) {
-        vec v;
-#pragma unroll
-        for (int i = 0; i < 14; ++i) v[i] = a.l[i];
-        return v;
+    // a b - c d for a d below 2p
+    static __device__ __forceinline__ fqx mul_sub(const fqx& a, const fqx& b, const fqx& c, const fqx& d) {
+        return x_mul2<FqX>(a, b, c, x_neg_lazy<FqX, 3>(d));
     }
-    static __device__ __forceinline__ fqx unpack(const vec& v) {
-        fqx a;
-#pragma unroll
-        for (int i = 0; i < 14; ++i) a.l[i] = v[i];
-        return a;
-    }
-    static __device__ __noinline__ vec mul_fn(vec a, vec b) { return pack(x_mul<FqX>(unpack(a), unpack(b))); }
-    static __device__ __noinline__ vec sqr_fn(vec a) { return pack(x_sqr<FqX>(unpack(a))); }
-    static __device__ __forceinline__ fqx mul(const fqx& a, const fqx& b) { return unpack(mul_fn(pack(a), pack(b))); }
-    static __device__ __forceinline__ fqx sqr(const fqx& a) { return unpack(sqr_fn(pack(a))); }
 };
 
 __device__ __forceinline__ bool ptx_is_inf(const PtX& p) { return x_limbs_zero<FqX>(p.zz); }
@@ -87,27 +65,36 @@ __device__ __forceinline__ PtX ptx_double_affine(const AffX& q) {
     return ptx_double(p);
 }
 
-// acc += q (madd-2008-s: 8M + 2S)
-__device__ __forceinline__ void ptx_madd(PtX& acc, const AffX& q) {
+// acc += q, or acc -= q when neg (madd-2008-s: 8M + 2S, the two products of Y3 under one reduction)
+__device__ __forceinline__ void ptx_madd(PtX& acc, const AffX& q, bool neg = false) {
     if (affx_is_inf(q)) return;
     if (ptx_is_inf(acc)) {
-        acc.x = q.x; acc.y = q.y; acc.zz = x_one<FqX>(); acc.zzz = x_one<FqX>();
+        acc.x = q.x; acc.y = neg ? x_sub<FqX, 2>(x_zero<FqX>(), q.y) : q.y;
+        acc.zz = x_one<FqX>(); acc.zzz = x_one<FqX>();
         return;
     }
+    fqx ys;   // +-y; the negative one carry-free (limbs below 2^30), which a first operand of x_mul may be
+#pragma unroll
+    for (int k = 0; k < FqX::L; ++k) ys.l[k] = neg ? FqX::bp3(k) - q.y.l[k] : q.y.l[k];
     const fqx U2 = qmul(q.x, acc.zz);
-    const fqx S2 = qmul(q.y, acc.zzz);
+    const fqx S2 = qmul(ys, acc.zzz);
     const fqx P = x_sub<FqX, 8>(U2, acc.x);   // < 10p
     const fqx R = x_sub<FqX, 4>(S2, acc.y);   // < 6p
     if (x_is_zero16<FqX>(P)) {
-        if (x_is_zero16<FqX>(R)) acc = ptx_double_affine(q);
-        else acc = ptx_identity();
+        if (x_is_zero16<FqX>(R)) {
+            AffX s;
+            s.x = q.x; s.y = neg ? x_sub<FqX, 2>(x_zero<FqX>(), q.y) : q.y;
+            acc = ptx_double_affine(s);
+        } else {
+            acc = ptx_identity();
+        }
         return;
     }
     const fqx PP = qsqr(P);
     const fqx PPP = qmul(P, PP);
     const fqx Q = qmul(acc.x, PP);
-    const fqx X3 = x_sub<FqX, 4>(x_sub<FqX, 2>(qsqr(R), PPP), x_add<FqX>(Q, Q));   // < 8p
-    const fqx Y3 = x_sub<FqX, 2>(qmul(R, x_sub<FqX, 8>(Q, X3)), qmul(acc.y, PPP));  // < 4p
+    const fqx X3 = x_sub_sub2<FqX, 6>(qsqr(R), PPP, Q);                                // R^2 - PPP - 2Q, < 8p
+    const fqx Y3 = MulInline::mul_sub(R, x_sub<FqX, 8>(Q, X3), acc.y, PPP);             // < 2p
     acc.x = X3;
     acc.y = Y3;
     acc.zz = qmul(acc.zz, PP);
@@ -136,8 +123,8 @@ __device__ __forceinline__ void ptx_add(PtX& acc, const PtX& q) {
     const fqx PP = M::sqr(P);
     const fqx PPP = M::mul(P, PP);
     const fqx Q = M::mul(U1, PP);
-    const fqx X3 = x_sub<FqX, 4>(x_sub<FqX, 2>(M::sqr(R), PPP), x_add<FqX>(Q, Q));
-    const fqx Y3 = x_sub<FqX, 2>(M::mul(R, x_sub<FqX, 8>(Q, X3)), M::mul(S1, PPP));
+    const fqx X3 = x_sub_sub2<FqX, 6>(M::sqr(R), PPP, Q);
+    const fqx Y3 = M::mul_sub(R, x_sub<FqX, 8>(Q, X3), S1, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = M::mul(M::mul(acc.zz, q.zz), PP);
@@ -158,10 +145,4 @@ __device__ __forceinline__ PtX ld_ptx(const g1x_xyzz_t* p) {
 __device__ __forceinline__ void st_ptx(g1x_xyzz_t* p, const PtX& a) {
     stx(&p->x, a.x); stx(&p->y, a.y); stx(&p->zz, a.zz); stx(&p->zzz, a.zzz);
 }
-// -y for a y < 2p (identity marker (0,0) must stay (0,0))
-__device__ __forceinline__ fqx fqx_neg_y(const fqx& y) {
-    if (x_limbs_zero<FqX>(y)) return y;
-    return x_sub<FqX, 2>(x_zero<FqX>(), y);
-}
-
 }  // namespace plonk

@@ -331,11 +331,11 @@ __global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* 
     if (gid < total_buckets) order[base[bin] + rank] = gid;
 }
 
-__device__ __forceinline__ AffX load_signed_point(const g1x_affine_t* points, uint32_t entry) {
-    AffX p = ld_affx(points + (entry & ~SIGN_BIT));
-    if (entry & SIGN_BIT) p.y = fqx_neg_y(p.y);
-    return p;
+// an entry is a point index with the sign of its digit in the top bit
+__device__ __forceinline__ AffX load_point(const g1x_affine_t* points, uint32_t entry) {
+    return ld_affx(points + (entry & ~SIGN_BIT));
 }
+__device__ __forceinline__ bool entry_neg(uint32_t entry) { return (entry & SIGN_BIT) != 0; }
 
 // ---- 5a. small buckets: one lane per bucket, visited in size order (order[0..n_big) are the big ones) ----
 __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __restrict__ points,
@@ -352,15 +352,18 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
     PtX acc = ptx_identity();
     // the next point is fetched (a random 128-byte read) while the current one is added
     uint32_t e_next = cnt ? src[0] : 0u;
-    AffX nxt = cnt ? load_signed_point(points, e_next) : AffX{x_zero<FqX>(), x_zero<FqX>()};
+    AffX nxt = cnt ? load_point(points, e_next) : AffX{x_zero<FqX>(), x_zero<FqX>()};
+    bool neg_next = entry_neg(e_next);
     e_next = cnt > 1 ? src[1] : 0u;
     for (uint32_t k = 0; k < cnt; ++k) {
         const AffX p = nxt;
+        const bool neg = neg_next;
         if (k + 1 < cnt) {
-            nxt = load_signed_point(points, e_next);
+            nxt = load_point(points, e_next);
+            neg_next = entry_neg(e_next);
             if (k + 2 < cnt) e_next = src[k + 2];
         }
-        ptx_madd(acc, p);
+        ptx_madd(acc, p, neg);
     }
     st_ptx(buckets + gid, acc);
 }
@@ -386,8 +389,9 @@ __global__ __launch_bounds__(256) void msm_bucket_split_kernel(const g1x_affine_
     const uint32_t* src = sorted + (live ? offsets[gid] : 0u);
     PtX acc = ptx_identity();
     for (uint32_t k = sub; k < cnt; k += LPB) {
-        const AffX p = load_signed_point(points, src[k]);
-        ptx_madd(acc, p);
+        const uint32_t e = src[k];
+        const AffX p = load_point(points, e);
+        ptx_madd(acc, p, entry_neg(e));
     }
 #pragma unroll 1
     for (uint32_t half = LPB >> 1; half > 0; half >>= 1) {
@@ -437,8 +441,9 @@ __global__ __launch_bounds__(256) void msm_huge_bucket_kernel(const g1x_affine_t
         const uint32_t lo = min(cnt, piece * len), hi = min(cnt, lo + len);
         PtX acc = ptx_identity();
         for (uint32_t k = lo + tid; k < hi; k += 256) {
-            const AffX p = load_signed_point(points, src[k]);
-            ptx_madd(acc, p);
+            const uint32_t e = src[k];
+            const AffX p = load_point(points, e);
+            ptx_madd(acc, p, entry_neg(e));
         }
         block_sum_256(acc, red, tid);
         if (tid == 0) st_ptx(pieces + (size_t)item * HUGE_PIECES + piece, acc);
@@ -467,8 +472,9 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
             const uint32_t cnt = counts[gid];
             const uint32_t* src = sorted + offsets[gid];
             for (uint32_t k = tid; k < cnt; k += 256) {
-                const AffX p = load_signed_point(points, src[k]);
-                ptx_madd(acc, p);
+                const uint32_t e = src[k];
+                const AffX p = load_point(points, e);
+                ptx_madd(acc, p, entry_neg(e));
             }
         }
         block_sum_256(acc, red, tid);
