@@ -87,6 +87,8 @@ inline host::fr_h to_host(const fr_t& d) {
 constexpr uint32_t NTT_INVERSE = PLONK_NTT_INVERSE;
 constexpr uint32_t NTT_COSET = PLONK_NTT_COSET;
 void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride);
+void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
+                size_t batch_stride);
 NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags);
 
 }  // namespace plonk

@@ -675,9 +675,10 @@ struct MsmWorkspace {
     bool timing = false;   // record the timing marks (msm_set_timing)
     MsmSlot slot[SLOTS];
     hipStream_t sort_stream = nullptr, bucket_stream = nullptr;
-    hipEvent_t ready = nullptr;
+    hipEvent_t ready = nullptr, filled = nullptr;
     ~MsmWorkspace() {
         if (ready) (void)hipEventDestroy(ready);
+        if (filled) (void)hipEventDestroy(filled);
         if (sort_stream) (void)hipStreamDestroy(sort_stream);
         if (bucket_stream) (void)hipStreamDestroy(bucket_stream);
     }
@@ -690,6 +691,7 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
         HIP_CHECK(hipStreamCreateWithFlags(&ws->sort_stream, hipStreamNonBlocking));
         HIP_CHECK(hipStreamCreateWithFlags(&ws->bucket_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ws->filled, hipEventDisableTiming));
         for (auto& s : ws->slot) {
             HIP_CHECK(hipEventCreateWithFlags(&s.sorted_ev, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s.buckets_ev, hipEventDisableTiming));
@@ -864,15 +866,15 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     return host::g1_to_affine(acc);
 }
 
-host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n) {
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler) {
     host::G1AffineH out;
-    msm_run_batch(ctx, pts, &scalars_dev, &n, 1, &out);
+    msm_run_batch(ctx, pts, &scalars_dev, &n, 1, &out, filler);
     return out;
 }
 
 // Up to MsmWorkspace::SLOTS independent MSMs against the same points, pipelined on the device.
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
-                   host::G1AffineH* out) {
+                   host::G1AffineH* out, const MsmFiller& filler) {
     for (int k = 0; k < count; ++k) PLONK_REQUIRE(n[k] <= pts.level_stride, "msm: more scalars than points");
     MsmWorkspace* ws = msm_workspace(ctx);
     for (int base = 0; base < count; base += MsmWorkspace::SLOTS) {
@@ -881,6 +883,12 @@ void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_de
         HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
         for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], false);
         for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], true);
+        if (filler && base + m == count) {
+            HIP_CHECK(hipStreamWaitEvent(ws->bucket_stream, ws->ready, 0));   // also when every MSM was empty
+            filler(ws->bucket_stream);
+            HIP_CHECK(hipEventRecord(ws->filled, ws->bucket_stream));
+            HIP_CHECK(hipStreamWaitEvent(ctx->stream, ws->filled, 0));
+        }
         for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
     }
 }

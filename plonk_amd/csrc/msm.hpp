@@ -1,5 +1,7 @@
 // Host-side declarations of the MSM / SRS module (msm.hip).
 #pragma once
+#include <functional>
+
 #include "common.hpp"
 #include "g1.cuh"
 #include "g1x.cuh"
@@ -30,9 +32,13 @@ constexpr size_t MSM_TABLE_MIN_POINTS = (size_t)1 << 10;
 
 uint32_t msm_window_bits(size_t n);
 uint32_t msm_table_bits(size_t n);
-host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n);
+// Work for the end of a batch: called once with the stream of the bucket kernels, after the last of
+// them is enqueued, so what it launches there runs beside the final (latency-bound) reduction instead
+// of after it.  msm_run / msm_run_batch return with ctx->stream ordered behind that work.
+typedef std::function<void(hipStream_t)> MsmFiller;
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler = nullptr);
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
-                   host::G1AffineH* out);
+                   host::G1AffineH* out, const MsmFiller& filler = nullptr);
 struct MsmTiming {
     float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;
     uint64_t entries;

@@ -379,7 +379,7 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
     return get_plan_shift(ctx, log_n, flags, host::Fr::from_u64(7));
 }
 
-static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride) {
+static void ntt_launch(Ctx* ctx, hipStream_t stream, NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride) {
     const uint32_t log_n = pl->log_n, P = pl->n_pass;
     if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
     if (!ctx->ntt_lds_attr_set) {   // per device, and a context belongs to one device
@@ -431,21 +431,28 @@ static void ntt_launch(Ctx* ctx, NttPlan* pl, fr_t* data, uint32_t batch, size_t
         const uint32_t tiles = 1u << (log_n - R - log_c);
         const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
         const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + ((size_t)1 << R) / 2 * 36 + 16;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, ctx->stream, a);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, a);
         HIP_CHECK(hipGetLastError());
         log_h += R;
     }
 }
 
 void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride) {
+    ntt_run_on(ctx, ctx->stream, data_dev, log_n, flags, batch, batch_stride);
+}
+
+// The same on another stream of the context.  The sweeps share one scratch buffer per context: the
+// caller orders this stream against every other transform of the context.
+void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
+                size_t batch_stride) {
     NttPlan* pl = ntt_get_plan(ctx, log_n, flags);
-    ntt_launch(ctx, pl, data_dev, batch, batch_stride);
+    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride);
 }
 
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
                    size_t batch_stride) {
     NttPlan* pl = get_plan_shift(ctx, log_n, flags, shift);
-    ntt_launch(ctx, pl, data_dev, batch, batch_stride);
+    ntt_launch(ctx, ctx->stream, pl, data_dev, batch, batch_stride);
 }
 
 }  // namespace plonk

@@ -248,17 +248,17 @@ host::G1AffineH g1_sum_affine(const plonk_g1* pts, size_t n) {
 }
 
 static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
-                                  const ShardInfo* shard = nullptr) {
+                                  const ShardInfo* shard = nullptr, const MsmFiller& filler = nullptr) {
     // kzg.rs:231-245.  Coefficients past the SRS must be zero (the reference strips trailing zeros
     // before its length check and panics otherwise).
     if (!shard || shard->world <= 1) {
         size_t m = std::min(len, srs->n);
         if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
-        return msm_run(ctx, msm_points(srs), coeffs, m);
+        return msm_run(ctx, msm_points(srs), coeffs, m, filler);
     }
     // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
     const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
-    host::G1AffineH part = msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo);
+    host::G1AffineH part = msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo, filler);
     plonk_g1 mine;
     g1_from_host(part, &mine);
     std::vector<plonk_g1> all(shard->world);
@@ -270,7 +270,7 @@ static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, 
 // Several commitments against the same SRS, overlapped on the device (independent MSMs on
 // separate streams).  Sharded runs exchange one partial sum per commitment.
 static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
-                         uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out) {
+                         uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out, const MsmFiller& filler = nullptr) {
     const fr_t* ptr[4];
     size_t len[4];
     const bool sharded = shard && shard->world > 1;
@@ -285,7 +285,7 @@ static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, co
             len[k] = hi - lo;
         }
     }
-    msm_run_batch(ctx, msm_points(srs), ptr, len, count, out);
+    msm_run_batch(ctx, msm_points(srs), ptr, len, count, out, filler);
     if (sharded) {
         std::vector<plonk_g1> mine(count), all((size_t)count * shard->world);
         for (int k = 0; k < count; ++k) g1_from_host(out[k], &mine[k]);
@@ -376,7 +376,10 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     {
         const fr_t* cp[3] = {CO[0], CO[1], CO[2]};
         const size_t cl[3] = {n + 2, n + 2, n + 2};
-        commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm);
+        // the wires' evaluations on the 4n coset (round 3 reads them; they depend on no challenge)
+        // are computed while the last commitment's reduction drains
+        commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm,
+                     [&](hipStream_t s) { ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4); });
     }
     tr.absorb_g1("a_comm", comm[0]);
     tr.absorb_g1("b_comm", comm[1]);
@@ -404,7 +407,8 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_blind(ctx, W[3], (uint32_t)n, b3, 3);
         poly_copy(ctx, CO[3], W[3], n + 3);
     }
-    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard);
+    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard,
+                         [&](hipStream_t s) { ntt_run_on(ctx, s, W[3], log_n + 2, NTT_COSET, 1, 0); });
     check_flag(ctx, ws);
     tr.absorb_g1("z_comm", comm[3]);
     const fr_h alpha = tr.squeeze_challenge("alpha");
@@ -419,7 +423,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         ntt_run(ctx, W[4], log_n, NTT_INVERSE, 1, 0);
         has_pi = true;
     }
-    ntt_run(ctx, W[0], log_n + 2, NTT_COSET, has_pi ? 5 : 4, n4);
+    if (has_pi) ntt_run(ctx, W[4], log_n + 2, NTT_COSET, 1, 0);
     quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
     ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
     poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
