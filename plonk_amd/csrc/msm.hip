@@ -872,25 +872,48 @@ host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev,
     return out;
 }
 
-// Up to MsmWorkspace::SLOTS independent MSMs against the same points, pipelined on the device.
+// Up to MSM_BATCH_MAX independent MSMs against the same points, pipelined on the device.  add() starts
+// one (its sort and bucket phases) as soon as its scalars are ready on ctx->stream, so the caller can
+// go on preparing the next scalars; finish() runs the reductions and collects the results.
+void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n) {
+    PLONK_REQUIRE(b.count < MSM_BATCH_MAX, "msm: batch is full");
+    PLONK_REQUIRE(n <= b.pts.level_stride, "msm: more scalars than points");
+    MsmWorkspace* ws = msm_workspace(ctx);
+    HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
+    b.scalars[b.count] = scalars_dev;
+    b.n[b.count] = n;
+    msm_enqueue(ctx, ws, b.count, b.pts, scalars_dev, n, false);
+    ++b.count;
+}
+
+void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFiller& filler) {
+    MsmWorkspace* ws = msm_workspace(ctx);
+    for (int k = 0; k < b.count; ++k) msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], true);
+    if (filler) {
+        // behind what ctx->stream held when the last MSM was added (not behind the reductions above)
+        if (b.count == 0) HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
+        HIP_CHECK(hipStreamWaitEvent(ws->bucket_stream, ws->ready, 0));
+        filler(ws->bucket_stream);
+        HIP_CHECK(hipEventRecord(ws->filled, ws->bucket_stream));
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream, ws->filled, 0));
+    }
+    for (int k = 0; k < b.count; ++k) out[k] = msm_collect(ws, k);
+    b.count = 0;
+}
+
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out, const MsmFiller& filler) {
+    static_assert(MSM_BATCH_MAX == MsmWorkspace::SLOTS, "one workspace slot per MSM of a batch");
     for (int k = 0; k < count; ++k) PLONK_REQUIRE(n[k] <= pts.level_stride, "msm: more scalars than points");
-    MsmWorkspace* ws = msm_workspace(ctx);
-    for (int base = 0; base < count; base += MsmWorkspace::SLOTS) {
-        const int m = std::min(MsmWorkspace::SLOTS, count - base);
-        HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
-        HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
-        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], false);
-        for (int k = 0; k < m; ++k) msm_enqueue(ctx, ws, k, pts, scalars_dev[base + k], n[base + k], true);
-        if (filler && base + m == count) {
-            HIP_CHECK(hipStreamWaitEvent(ws->bucket_stream, ws->ready, 0));   // also when every MSM was empty
-            filler(ws->bucket_stream);
-            HIP_CHECK(hipEventRecord(ws->filled, ws->bucket_stream));
-            HIP_CHECK(hipStreamWaitEvent(ctx->stream, ws->filled, 0));
-        }
-        for (int k = 0; k < m; ++k) out[base + k] = msm_collect(ws, k);
+    MsmBatch b;
+    b.pts = pts;
+    for (int base = 0; base < count; base += MSM_BATCH_MAX) {
+        const int m = std::min(MSM_BATCH_MAX, count - base);
+        for (int k = 0; k < m; ++k) msm_batch_add(ctx, b, scalars_dev[base + k], n[base + k]);
+        msm_batch_finish(ctx, b, out + base, base + m == count ? filler : MsmFiller());
     }
+    if (count == 0 && filler) msm_batch_finish(ctx, b, out, filler);
 }
 
 // Timing marks are recorded only while enabled (extra events on the MSM streams).

@@ -39,6 +39,16 @@ typedef std::function<void(hipStream_t)> MsmFiller;
 host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler = nullptr);
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
                    host::G1AffineH* out, const MsmFiller& filler = nullptr);
+// The same in two steps, for a caller that prepares the scalar vectors one after the other.
+constexpr int MSM_BATCH_MAX = 3;
+struct MsmBatch {
+    MsmPoints pts;
+    int count = 0;
+    const fr_t* scalars[MSM_BATCH_MAX];
+    size_t n[MSM_BATCH_MAX];
+};
+void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n);
+void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFiller& filler = nullptr);
 struct MsmTiming {
     float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;
     uint64_t entries;

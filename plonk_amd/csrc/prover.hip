@@ -268,25 +268,25 @@ static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, 
 }
 
 // Several commitments against the same SRS, overlapped on the device (independent MSMs on
-// separate streams).  Sharded runs exchange one partial sum per commitment.
-static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
-                         uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out, const MsmFiller& filler = nullptr) {
-    const fr_t* ptr[4];
-    size_t len[4];
-    const bool sharded = shard && shard->world > 1;
-    for (int k = 0; k < count; ++k) {
-        if (!sharded) {
-            if (lens[k] > srs->n) poly_nonzero_check(ctx, coeffs[k], (uint32_t)srs->n, (uint32_t)lens[k], flag_dev);
-            ptr[k] = coeffs[k];
-            len[k] = std::min(lens[k], srs->n);
-        } else {
-            const size_t lo = std::min(shard->lo, lens[k]), hi = std::min(shard->lo + srs->n, lens[k]);
-            ptr[k] = coeffs[k] + lo;
-            len[k] = hi - lo;
-        }
+// separate streams).  commit_add starts one as soon as its coefficients are ready on ctx->stream;
+// commit_finish collects them.  Sharded runs exchange one partial sum per commitment.
+static void commit_add(Ctx* ctx, const Srs* srs, MsmBatch& b, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
+                       const ShardInfo* shard) {
+    if (b.count == 0) b.pts = msm_points(srs);
+    if (!(shard && shard->world > 1)) {
+        if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
+        msm_batch_add(ctx, b, coeffs, std::min(len, srs->n));
+    } else {   // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
+        const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
+        msm_batch_add(ctx, b, coeffs + lo, hi - lo);
     }
-    msm_run_batch(ctx, msm_points(srs), ptr, len, count, out, filler);
-    if (sharded) {
+}
+
+static void commit_finish(Ctx* ctx, MsmBatch& b, const ShardInfo* shard, host::G1AffineH* out,
+                          const MsmFiller& filler = nullptr) {
+    const int count = b.count;
+    msm_batch_finish(ctx, b, out, filler);
+    if (shard && shard->world > 1) {
         std::vector<plonk_g1> mine(count), all((size_t)count * shard->world);
         for (int k = 0; k < count; ++k) g1_from_host(out[k], &mine[k]);
         const int rc = shard->allgather(shard->user, mine.data(), sizeof(plonk_g1) * count, all.data());
@@ -297,6 +297,13 @@ static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, co
             out[k] = g1_sum_affine(col.data(), col.size());
         }
     }
+}
+
+static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
+                         uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out, const MsmFiller& filler = nullptr) {
+    MsmBatch b;
+    for (int k = 0; k < count; ++k) commit_add(ctx, srs, b, coeffs[k], lens[k], flag_dev, shard);
+    commit_finish(ctx, b, shard, out, filler);
 }
 
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
@@ -447,6 +454,13 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
 
     // ---- round 4 (prover.rs:577-641) ----
     const fr_h zeta_omega = Fr::mul(zeta, pk->omega);
+    // W_{zeta omega} = (z - z(zeta omega)) / (X - zeta omega) (:815-816) needs zeta alone -- the value
+    // subtracted from the constant term changes the remainder, not the quotient -- so its commitment
+    // is started here and runs underneath rounds 4 and 5; it enters the proof in the reference's order.
+    MsmBatch openings;
+    HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
+    poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq2.p, ws->totals);
+    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard);
     fr_h e6[6];
     {
         EvalArgs ea;
@@ -523,14 +537,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
-        // W_{zeta omega} = (z - z_bar_omega) / (X - zeta omega)  (:815-816)
-        poly_copy(ctx, ws->wnum.p, CO[3], n + 3);
-        poly_poke(ctx, ws->wnum.p, 0, zw_bar, true);
-        HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
-        poly_div_linear(ctx, ws->wnum.p, (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq2.p, ws->totals);
-        const fr_t* cp[2] = {ws->wq.p, ws->wq2.p};
-        const size_t cl[2] = {wlen - 1, n + 2};
-        commit_batch(ctx, srs, cp, cl, 2, ws->flag.p, shard, comm + 7);
+        commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard);
+        host::G1AffineH w[2];
+        commit_finish(ctx, openings, shard, w);
+        comm[7] = w[1];   // W_zeta
+        comm[8] = w[0];   // W_{zeta omega}
         check_flag(ctx, ws);
     }
 
