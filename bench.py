@@ -191,7 +191,12 @@ def main():
                              "achieved": round(ntt_rate / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": round(ntt_rate / HBM_PEAK, 4),
                              "traffic": pmc_traffic("ntt_pass_kernel", "ntt") if log4 == 22 else None,
-                             "avg_launch_ms": round(ntt_ms / sweeps, 4), "algorithmic_bytes_per_launch": ntt_bytes / sweeps},
+                             "avg_launch_ms": round(ntt_ms / sweeps, 4), "algorithmic_bytes_per_launch": ntt_bytes / sweeps,
+                             # a 255-bit butterfly is one Fr product per 64 bytes moved: at the measured product
+                             # ceiling the transform cannot pass ~11 % of the HBM rate, so the product rate is
+                             # the bound that bites ((N/2) log2 N butterflies per transform)
+                             "valu_frac": round((1 << (log4 - 1)) * log4 / (ntt_ms * 1e-3) / fr_peak, 4),
+                             "note": "integer-VALU bound: valu_frac = butterfly products/s over the measured Fr product peak"},
         }
         if world == 1:
             # the same proof from host witness vectors (3 n 32 bytes over PCIe inside the call): never `value`

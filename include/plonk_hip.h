@@ -190,6 +190,10 @@ int32_t plonk_msm_last_timing(plonk_ctx* ctx, plonk_msm_timing* out);
 /* ---- encodings (host only, no device work) ---- */
 /* G1Affine::to_compressed_bytes (curve.rs:84-88). */
 int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]);
+/* G1Affine::from_compressed_bytes (curve.rs:90-93; what the Deserialize impl of curve.rs:436-450
+ * reads a point from): PLONK_E_INVALID for a cleared compression bit, x >= q, an x with no point
+ * on the curve, or a point outside the order-r subgroup. */
+int32_t plonk_g1_decompress(const uint8_t in[48], plonk_g1* out);
 /* Fr::to_bytes (field.rs:106-114): canonical little-endian. */
 int32_t plonk_fr_to_bytes(const plonk_fr* a, uint8_t out[32]);
 /* Fr::from_bytes (field.rs:117-125): PLONK_E_INVALID when the integer is >= r. */
@@ -197,6 +201,9 @@ int32_t plonk_fr_from_bytes(const uint8_t in[32], plonk_fr* out);
 /* 624-byte wire image: a,b,c,z,t_lo,t_mid,t_hi compressed, six evaluations, w_zeta,
  * w_zeta_omega compressed (the field order of trace.rs:255-332 CompactProof). */
 int32_t plonk_proof_serialize(const plonk_proof* proof, uint8_t out[PLONK_PROOF_WIRE_BYTES]);
+/* Inverse of plonk_proof_serialize (each point through plonk_g1_decompress, each scalar through
+ * plonk_fr_from_bytes); PLONK_E_INVALID if any element is rejected, *proof untouched then. */
+int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_proof* proof);
 /* Transcript::squeeze_challenge chain of the prover (transcript.rs:39-131), exposed so callers
  * can re-derive beta, gamma, alpha, zeta, v, u from a proof: out[6] Montgomery Fr. */
 int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_inputs, size_t n_public_inputs,

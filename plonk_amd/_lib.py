@@ -90,6 +90,8 @@ SIGNATURES = {
     "plonk_msm_set_timing": (_i32, [_vp, _i32]),
     "plonk_msm_last_timing": (_i32, [_vp, C.POINTER(MsmTiming)]),
     "plonk_g1_compress": (_i32, [_vp, _vp]),
+    "plonk_g1_decompress": (_i32, [_vp, _vp]),
+    "plonk_proof_deserialize": (_i32, [_vp, _vp]),
     "plonk_fr_to_bytes": (_i32, [_vp, _vp]),
     "plonk_fr_from_bytes": (_i32, [_vp, _vp]),
     "plonk_proof_serialize": (_i32, [_vp, _vp]),

@@ -382,6 +382,69 @@ class Proof:
             raise PlonkError(rc, "plonk_proof_serialize")
         return bytes(out)
 
+    @classmethod
+    def from_bytes(cls, data):
+        """Inverse of to_bytes; every point is validated as G1Affine::from_compressed_bytes does
+        (curve.rs:90-93)."""
+        if len(data) != _lib.PROOF_WIRE_BYTES:
+            raise ValueError("proof: expected %d bytes" % _lib.PROOF_WIRE_BYTES)
+        raw = _lib.Proof()
+        buf = (C.c_uint8 * _lib.PROOF_WIRE_BYTES).from_buffer_copy(data)
+        rc = lib.plonk_proof_deserialize(buf, C.byref(raw))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_proof_deserialize")
+        return cls(raw)
+
+    def to_compact(self):
+        """The CompactProof JSON object of trace.rs:255-332: points as {compressed, x, y}
+        (curve.rs:418-434: 0x-hex of the 48-byte compressed form and of the two big-endian
+        coordinates, "infinity" for the identity), scalars as {full, short} (field.rs:294-308:
+        0x-hex of the canonical value, big-endian, and its first 10 / last 8 characters)."""
+        d = self.to_dict()
+
+        def g1(key):
+            pt = d[key]
+            comp = (C.c_uint8 * 48)()
+            rc = lib.plonk_g1_compress(C.byref(getattr(self.raw, key)), comp)
+            if rc != 0:
+                raise PlonkError(rc, "plonk_g1_compress")
+            xy = ("infinity", "infinity") if pt is None else tuple("0x%096x" % v for v in pt)
+            return {"compressed": "0x" + bytes(comp).hex(), "x": xy[0], "y": xy[1]}
+
+        def fr(key):
+            full = "0x%064x" % d[key]
+            return {"full": full, "short": full[:10] + "..." + full[-8:]}
+
+        return {
+            "round1": {"a": g1("a_comm"), "b": g1("b_comm"), "c": g1("c_comm")},
+            "round2": {"z": g1("z_comm")},
+            "round3": {"t_lo": g1("t_lo_comm"), "t_mid": g1("t_mid_comm"), "t_hi": g1("t_hi_comm")},
+            "round4": {"a_zeta": fr("a_eval"), "b_zeta": fr("b_eval"), "c_zeta": fr("c_eval"),
+                       "s_sigma1_zeta": fr("s_sigma1_eval"), "s_sigma2_zeta": fr("s_sigma2_eval"),
+                       "z_omega_zeta": fr("z_omega_eval")},
+            "round5": {"w_zeta": g1("w_zeta_comm"), "w_zeta_omega": g1("w_zeta_omega_comm")},
+        }
+
+    @classmethod
+    def from_compact(cls, obj):
+        """What serde's Deserialize of CompactProof reads: `compressed` of every point
+        (curve.rs:436-450) and `full` of every scalar (field.rs:310-320)."""
+        def g1(o):
+            h = o["compressed"]
+            return bytes.fromhex(h[2:] if h.startswith("0x") else h)
+
+        def fr(o):
+            h = o["full"]
+            return int(h[2:] if h.startswith("0x") else h, 16).to_bytes(32, "little")
+
+        r1, r3, r4, r5 = obj["round1"], obj["round3"], obj["round4"], obj["round5"]
+        wire = b"".join([g1(r1["a"]), g1(r1["b"]), g1(r1["c"]), g1(obj["round2"]["z"]),
+                         g1(r3["t_lo"]), g1(r3["t_mid"]), g1(r3["t_hi"]),
+                         fr(r4["a_zeta"]), fr(r4["b_zeta"]), fr(r4["c_zeta"]), fr(r4["s_sigma1_zeta"]),
+                         fr(r4["s_sigma2_zeta"]), fr(r4["z_omega_zeta"]),
+                         g1(r5["w_zeta"]), g1(r5["w_zeta_omega"])])
+        return cls.from_bytes(wire)
+
     def challenges(self, public_inputs=()):
         """beta, gamma, alpha, zeta, v, u re-derived from the proof (verifier.rs:51-92)."""
         pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])

@@ -446,6 +446,32 @@ int32_t plonk_g1_compress(const plonk_g1* p, uint8_t out[48]) {
     return PLONK_OK;
 }
 
+int32_t plonk_g1_decompress(const uint8_t in[48], plonk_g1* out) {
+    if (!in || !out) return PLONK_E_INVALID;
+    host::G1AffineH a;
+    if (!host::g1_decompress(in, &a)) return PLONK_E_INVALID;
+    g1_from_host(a, out);
+    return PLONK_OK;
+}
+
+int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_proof* proof) {
+    if (!in || !proof) return PLONK_E_INVALID;
+    plonk_proof pr;
+    memset(&pr, 0, sizeof(pr));
+    plonk_g1* g[9] = {&pr.a_comm, &pr.b_comm, &pr.c_comm, &pr.z_comm, &pr.t_lo_comm,
+                      &pr.t_mid_comm, &pr.t_hi_comm, &pr.w_zeta_comm, &pr.w_zeta_omega_comm};
+    plonk_fr* f[6] = {&pr.a_eval, &pr.b_eval, &pr.c_eval, &pr.s_sigma1_eval, &pr.s_sigma2_eval, &pr.z_omega_eval};
+    const uint8_t* p = in;
+    for (int k = 0; k < 7; ++k, p += 48)
+        if (plonk_g1_decompress(p, g[k]) != PLONK_OK) return PLONK_E_INVALID;
+    for (int k = 0; k < 6; ++k, p += 32)
+        if (plonk_fr_from_bytes(p, f[k]) != PLONK_OK) return PLONK_E_INVALID;
+    for (int k = 7; k < 9; ++k, p += 48)
+        if (plonk_g1_decompress(p, g[k]) != PLONK_OK) return PLONK_E_INVALID;
+    *proof = pr;
+    return PLONK_OK;
+}
+
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second) {
     if (!ctx || !muls_per_second || which > 3) return PLONK_E_INVALID;
     API_BEGIN(ctx)

@@ -338,6 +338,57 @@ inline G1AffineH g1_generator() {
     return g;
 }
 
+// curve.rs:90-93 from_compressed_bytes = ark-bls12-381 0.4.0 deserialize_compressed with validation:
+// the compression bit must be set; the infinity bit alone decides the identity; x must be below q;
+// y is the root of x^3 + 4 picked by the sort bit; the point must lie in the order-r subgroup.
+inline bool g1_decompress(const uint8_t in[48], G1AffineH* out) {
+    if (!(in[0] & 0x80)) return false;
+    if (in[0] & 0x40) {
+        out->x = Fq::zero(); out->y = Fq::zero(); out->inf = true;
+        return true;
+    }
+    fq_h x;
+    for (int i = 0; i < 6; ++i) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; ++b) {
+            uint8_t byte = in[47 - (i * 8 + b)];
+            if (i == 5 && b == 7) byte &= 0x1f;
+            w |= (uint64_t)byte << (8 * b);
+        }
+        x.l[i] = w;
+    }
+    if (Fq::geq_p(x)) return false;
+    const fq_h xm = Fq::to_mont(x);
+    const fq_h rhs = Fq::add(Fq::mul(Fq::sqr(xm), xm), Fq::from_u64(4));
+    // q = 3 mod 4: a root, if any, is rhs^((q+1)/4)
+    uint64_t e[6];
+    u128 carry = 1;
+    for (int i = 0; i < 6; ++i) {
+        carry += HFqP::P[i];
+        e[i] = (uint64_t)carry;
+        carry >>= 64;
+    }
+    for (int i = 0; i < 6; ++i) e[i] = (e[i] >> 2) | (i < 5 ? e[i + 1] << 62 : 0);
+    fq_h y = Fq::pow_limbs(rhs, e, 6);
+    if (!(Fq::sqr(y) == rhs)) return false;
+    // the sort bit asks for the larger of y and q - y
+    const fq_h ny = Fq::neg(y);
+    const fq_h yc = Fq::from_mont(y), nyc = Fq::from_mont(ny);
+    bool y_larger = false;
+    for (int i = 5; i >= 0; --i) {
+        if (yc.l[i] != nyc.l[i]) { y_larger = yc.l[i] > nyc.l[i]; break; }
+    }
+    const bool want_larger = (in[0] & 0x20) != 0;
+    out->x = xm;
+    out->y = (y_larger == want_larger) ? y : ny;
+    out->inf = false;
+    // subgroup check: r P = identity
+    const fr_h r_minus_1 = Fr::from_mont(Fr::neg(Fr::one()));   // r - 1, canonical
+    G1XyzzH t = g1_mul_limbs(g1_from_affine(*out), r_minus_1.l, 4);
+    t = g1_add(t, g1_from_affine(*out));
+    return g1_is_inf(t);
+}
+
 inline bool g1_on_curve(const G1AffineH& a) {
     if (a.inf) return true;
     fq_h lhs = Fq::sqr(a.y);

@@ -73,6 +73,69 @@ def test_proof_serialize_and_challenges_match_oracle():
     assert pr.challenges([]) == [int(c, 16) for c in e["challenges"]]
 
 
+def test_g1_decompress_matches_oracle_and_rejects_what_arkworks_rejects():
+    """curve.rs:90-93: compression bit required, x < q, x on the curve, point in the r-subgroup."""
+    from plonk_amd import _lib, api
+    G = curve.G1_GEN
+    for pt in (G, curve.affine_neg(G), curve.to_affine(curve.scalar_mul(G, 7)),
+               curve.to_affine(curve.scalar_mul(G, R_MOD - 3)), None):
+        enc = curve.compress(pt)
+        out = _lib.G1()
+        assert _lib.lib.plonk_g1_decompress((C.c_uint8 * 48)(*enc), C.byref(out)) == 0
+        assert api._g1_value(out) == pt == curve.decompress(enc)
+    good = bytearray(curve.compress(G))
+
+    def rejected(b):
+        return _lib.lib.plonk_g1_decompress((C.c_uint8 * 48)(*b), C.byref(_lib.G1())) == _lib.PLONK_E_INVALID
+
+    b = bytearray(good); b[0] &= 0x7F
+    assert rejected(b)                                   # not flagged as compressed
+    b = bytearray((curve.Q_MOD).to_bytes(48, "big")); b[0] |= 0x80
+    assert rejected(b)                                   # x = q is not a field element
+    # x with x^3 + 4 a non-residue
+    x = 1
+    while pow((x ** 3 + 4) % curve.Q_MOD, (curve.Q_MOD - 1) // 2, curve.Q_MOD) == 1:
+        x += 1
+    b = bytearray(x.to_bytes(48, "big")); b[0] |= 0x80
+    assert rejected(b)
+    # a curve point outside the r-torsion (the cofactor is not 1, so most x qualify)
+    x = 1
+    while True:
+        rhs = (x ** 3 + 4) % curve.Q_MOD
+        y = pow(rhs, (curve.Q_MOD + 1) // 4, curve.Q_MOD)
+        if y * y % curve.Q_MOD == rhs:
+            # r P as (r - 1) P + P: scalar_mul reduces its scalar mod r
+            rp = curve.jac_add(curve.scalar_mul((x, y), R_MOD - 1), curve.to_jac((x, y)))
+            if not curve.jac_is_id(rp):
+                break
+        x += 1
+    b = bytearray(x.to_bytes(48, "big")); b[0] |= 0x80
+    assert rejected(b)
+
+
+def test_compact_proof_json_round_trip():
+    """trace.rs:255-332 layout; curve.rs:418-450 and field.rs:294-320 element encodings."""
+    import json
+    from plonk_amd import api
+    from conftest import golden
+    e = [x for x in golden("proofs.json") if x["name"] == "c2_range_proof_255"][0]
+    wire = bytes.fromhex(e["proof"])
+    pr = api.Proof.from_bytes(wire)
+    assert pr.to_bytes() == wire
+    obj = json.loads(json.dumps(pr.to_compact()))
+    assert list(obj) == ["round1", "round2", "round3", "round4", "round5"]
+    assert list(obj["round4"]) == ["a_zeta", "b_zeta", "c_zeta", "s_sigma1_zeta", "s_sigma2_zeta", "z_omega_zeta"]
+    a = curve.decompress(wire[:48])
+    assert obj["round1"]["a"] == {"compressed": "0x" + wire[:48].hex(), "x": "0x%096x" % a[0], "y": "0x%096x" % a[1]}
+    a_eval = int.from_bytes(wire[7 * 48:7 * 48 + 32], "little")
+    full = "0x%064x" % a_eval
+    assert obj["round4"]["a_zeta"] == {"full": full, "short": full[:10] + "..." + full[-8:]}
+    assert api.Proof.from_compact(obj).to_bytes() == wire
+    bad = bytearray(wire); bad[0] &= 0x7F
+    with pytest.raises(Exception):
+        api.Proof.from_bytes(bytes(bad))
+
+
 def test_no_gpu_fails_loudly():
     """Without a HIP device the product must raise, never fall back to a CPU path."""
     import torch
