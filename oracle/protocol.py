@@ -379,11 +379,27 @@ class Srs:
     def __init__(self, tau, max_degree):
         self.max_degree = max_degree
         self.tau = tau % R_MOD  # kept: the oracle's trapdoor checks need it
+        self._g2_tau = None
         self.g1_powers = []
         tp = 1
         for _ in range(max_degree + 1):
             self.g1_powers.append(to_affine(scalar_mul(curve.G1_GEN, tp)))
             tp = tp * tau % R_MOD
+
+
+    @property
+    def g2_generator(self):
+        """kzg.rs:32."""
+        from . import pairing
+        return pairing.G2_GEN
+
+    @property
+    def g2_tau(self):
+        """kzg.rs:34,86: [tau]_2, what the verifier's pairing check is taken against."""
+        from . import pairing
+        if self._g2_tau is None:
+            self._g2_tau = pairing.g2_mul(pairing.G2_GEN, self.tau)
+        return self._g2_tau
 
 
 def commit(coeffs, srs, use_trapdoor=False):
@@ -601,7 +617,22 @@ def proof_to_bytes(proof):
 def verify(vk, srs, proof, public_inputs):
     """verifier.rs:42-314.  The final check e(W, [tau]_2) == e(Rhs, [1]_2) (:309-314) is
     evaluated with the SRS trapdoor as tau*W == Rhs in G1, which is the same statement for
-    [tau]_2 = tau*[1]_2 (kzg.rs:86)."""
+    [tau]_2 = tau*[1]_2 (kzg.rs:86).  verify_pairing evaluates it as the reference does."""
+    w_comb, right = verifier_points(vk, proof, public_inputs)
+    return to_affine(scalar_mul(w_comb, srs.tau)) == right
+
+
+def verify_pairing(vk, g2_tau, proof, public_inputs):
+    """verifier.rs:42-314 with the pairing check of :309-314, pairing_check(w_combined, [tau]_2,
+    right_inner, [1]_2): needs only the public half of the SRS."""
+    from . import pairing
+    w_comb, right = verifier_points(vk, proof, public_inputs)
+    return pairing.pairing_check(w_comb, g2_tau, right, pairing.G2_GEN)
+
+
+def verifier_points(vk, proof, public_inputs):
+    """verifier.rs:42-300: transcript replay and the two G1 sides of the final check,
+    (w_combined, right_inner), affine."""
     n, omega, k1, k2 = vk["n"], vk["omega"], vk["k1"], vk["k2"]
     tr = Transcript(b"PLONK-v1")
     for i, pi in enumerate(public_inputs):
@@ -670,5 +701,4 @@ def verify(vk, srs, proof, public_inputs):
     right = jac_add(f_comm, sm(proof["w_zeta_comm"], zeta))  # :296-299
     right = jac_add(right, sm(proof["w_zeta_omega_comm"], u * zeta_omega % R_MOD))
     right = jac_add(right, jac_neg(e_comm))
-    lhs = scalar_mul(to_affine(w_comb), srs.tau)
-    return to_affine(lhs) == to_affine(right)
+    return to_affine(w_comb), to_affine(right)

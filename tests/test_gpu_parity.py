@@ -425,6 +425,13 @@ def test_prove_full_size_verifies(ctx):
     bad = dict(proof.to_dict())
     bad["a_eval"] = (bad["a_eval"] + 1) % R_MOD
     assert not P.verify(vk, _S, bad, [])
+    # and as the reference's verifier checks it (verifier.rs:309-314): the pairing against [tau]_2,
+    # on the proof as it comes back from the JSON wire format
+    from oracle import pairing
+    g2_tau = pairing.g2_mul(pairing.G2_GEN, circ.tau)
+    wire = pa.Proof.from_compact(proof.to_compact()).to_dict()
+    assert P.verify_pairing(vk, g2_tau, wire, [])
+    assert not P.verify_pairing(vk, g2_tau, bad, [])
 
 
 def test_msm_window_table_degenerate_points(ctx):

@@ -191,6 +191,40 @@ def test_preprocess_and_prove_verify():
     assert len(P.proof_to_bytes(proof)) == 624
 
 
+def test_pairing_properties():
+    """What curve.rs:535-544 checks of the pairing: bilinearity and non-degeneracy; plus the
+    order of GT elements and of the G2 generator."""
+    from oracle import pairing as pr
+    G, H = curve.G1_GEN, pr.G2_GEN
+    assert pr.g2_is_on_curve(H) and pr.g2_mul(H, R_MOD) is None
+    e = pr.pairing(G, H)
+    assert e != pr.F12_ONE and pr.f12_pow(e, R_MOD) == pr.F12_ONE
+    a, b = 0x1234567, R_MOD - 5
+    aG = curve.to_affine(curve.scalar_mul(G, a))
+    bH = pr.g2_mul(H, b)
+    assert pr.pairing(aG, bH) == pr.f12_pow(e, a * b % R_MOD)
+    assert pr.pairing(aG, H) == pr.pairing(G, pr.g2_mul(H, a))
+    assert pr.pairing(None, H) == pr.F12_ONE and pr.pairing(G, None) == pr.F12_ONE
+    assert pr.pairing_check(aG, bH, curve.to_affine(curve.scalar_mul(G, a * b % R_MOD)), H)
+    assert not pr.pairing_check(aG, bH, curve.to_affine(curve.scalar_mul(G, a * b % R_MOD + 1)), H)
+    assert pr.multi_pairing([(G, H), (curve.affine_neg(G), H)]) == pr.F12_ONE
+
+
+def test_verify_with_the_pairing_agrees_with_the_trapdoor_form():
+    """verifier.rs:309-314 evaluated as the reference does, against [tau]_2 (kzg.rs:86) alone."""
+    cs = P.range_proof_circuit(8, 42)
+    srs = P.Srs(0xABCDEF123456789, cs.n + 10)
+    pk, vk, perm, dom = P.preprocess(cs, srs)
+    rng = random.Random(11)
+    proof = P.prove(cs, pk, perm, dom, srs, [42], [rng.randrange(R_MOD) for _ in range(11)])
+    assert P.verify_pairing(vk, srs.g2_tau, proof, [42])
+    assert not P.verify_pairing(vk, srs.g2_tau, proof, [43])
+    bad = dict(proof, z_omega_eval=(proof["z_omega_eval"] + 1) % R_MOD)
+    assert not P.verify_pairing(vk, srs.g2_tau, bad, [42])
+    from oracle import pairing as pr
+    assert not P.verify_pairing(vk, pr.g2_mul(pr.G2_GEN, srs.tau + 1), proof, [42])   # another SRS
+
+
 def test_golden_ntt():
     for e in golden("ntt.json"):
         n = e["n"]
