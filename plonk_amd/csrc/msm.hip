@@ -284,14 +284,19 @@ __global__ __launch_bounds__(1024) void msm_fine_scatter_kernel(const uint2* __r
 __device__ __forceinline__ uint32_t order_bin(uint32_t cnt, BucketClasses k) {  // bin 0 = huge, 1 = big, then by size
     return cnt >= k.huge ? 0u : (cnt > k.big ? 1u : 2u + ((k.big - cnt) >> k.shift));
 }
+// A workgroup covers ORDER_PER_LANE * 256 buckets: the per-bin totals of a workgroup meet the other
+// workgroups' in global atomics on the same few dozen addresses, so there should be few workgroups.
+static constexpr uint32_t ORDER_PER_LANE = 8;
 __global__ __launch_bounds__(256) void msm_order_hist_kernel(const uint32_t* __restrict__ counts, uint32_t total_buckets,
                                                               BucketClasses classes, uint32_t* __restrict__ bins) {
     __shared__ uint32_t h[ORDER_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < total_buckets) {
-        atomicAdd(&h[order_bin(counts[gid], classes)], 1u);
+    const uint32_t first = blockIdx.x * (256 * ORDER_PER_LANE) + threadIdx.x;
+#pragma unroll
+    for (uint32_t j = 0; j < ORDER_PER_LANE; ++j) {
+        const uint32_t gid = first + j * 256;
+        if (gid < total_buckets) atomicAdd(&h[order_bin(counts[gid], classes)], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
@@ -319,16 +324,25 @@ __global__ __launch_bounds__(256) void msm_order_scatter_kernel(const uint32_t* 
     __shared__ uint32_t base[ORDER_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t bin = 0, rank = 0;
-    if (gid < total_buckets) {
-        bin = order_bin(counts[gid], classes);
-        rank = atomicAdd(&h[bin], 1u);
+    const uint32_t first = blockIdx.x * (256 * ORDER_PER_LANE) + threadIdx.x;
+    uint32_t bin[ORDER_PER_LANE], rank[ORDER_PER_LANE];
+#pragma unroll
+    for (uint32_t j = 0; j < ORDER_PER_LANE; ++j) {
+        const uint32_t gid = first + j * 256;
+        bin[j] = 0; rank[j] = 0;
+        if (gid < total_buckets) {
+            bin[j] = order_bin(counts[gid], classes);
+            rank[j] = atomicAdd(&h[bin[j]], 1u);
+        }
     }
     __syncthreads();
     if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
-    if (gid < total_buckets) order[base[bin] + rank] = gid;
+#pragma unroll
+    for (uint32_t j = 0; j < ORDER_PER_LANE; ++j) {
+        const uint32_t gid = first + j * 256;
+        if (gid < total_buckets) order[base[bin[j]] + rank[j]] = gid;
+    }
 }
 
 // an entry is a point index with the sign of its digit in the top bit
@@ -791,9 +805,10 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
                        num_wg, low_bits, s.part_hist.p);
     hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p,
                        s.wg_offsets.p, num_wg, low_bits, total_buckets, s.part_hist.p, s.counts.p, s.offsets.p, s.sorted.p);
-    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p);
+    const uint32_t oblk = (total_buckets + 256 * ORDER_PER_LANE - 1) / (256 * ORDER_PER_LANE);
+    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(oblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
-    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(bblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p,
+    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(oblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p,
                        s.order.p);
     if (s.timed) {
         HIP_CHECK(hipMemcpyAsync(s.host_entries, s.wg_offsets.p + (matrix - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
