@@ -38,12 +38,12 @@ def cpu_baseline(log_n):
     from oracle import cref
     n = 1 << log_n
     rng = np.random.default_rng(1)
-    ls = min(log_n, 20)
+    ls = min(log_n + 2, 22)
     a = rng.integers(0, 1 << 62, size=(1 << ls, 4), dtype=np.uint64)
     t = time.perf_counter(); cref.ntt(a, 0); t_ntt = time.perf_counter() - t
     def ntt_time(lg):
         return t_ntt * ((1 << lg) * lg) / ((1 << ls) * ls)
-    lm = min(log_n, 16)
+    lm = min(log_n, 18)
     m = 1 << lm
     pts = np.zeros((m, 12), dtype=np.uint64)
     g = cref.points_array([__import__("oracle.curve", fromlist=["G1_GEN"]).G1_GEN])[0]
@@ -53,7 +53,7 @@ def cpu_baseline(log_n):
     c_of = lambda k: 3 if k < 32 else int(math.log(k)) + 2
     work = lambda k: k * math.ceil(255 / c_of(k)) + 2 * (1 << c_of(k)) * math.ceil(255 / c_of(k))
     t_msm_n = t_msm * work(n) / work(m)
-    q = 1 << min(log_n + 2, 13)
+    q = 1 << min(log_n + 2, 16)
     ext = rng.integers(0, 1 << 62, size=(15, 4 * n if 4 * n <= q else q, 4), dtype=np.uint64)
     nn = ext.shape[1] // 4
     t = time.perf_counter(); cref.quotient(ext, nn, 3, 5, 7, 6, 7, 0, ext.shape[1]); t_q = (time.perf_counter() - t) / ext.shape[1]
