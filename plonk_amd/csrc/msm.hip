@@ -69,7 +69,9 @@ struct DigitIter {
 //                    (bin, g) its own output run; the entries go there as (payload, gid low bits).
 //            fine:   one workgroup per coarse bin sorts its run by the low bits in LDS and emits
 //                    the per-bucket counts / offsets and the final entry list. ----
-constexpr uint32_t SORT_SLAB = 1024;       // scalars per coarse workgroup (256 lanes x 4)
+constexpr uint32_t SORT_LANES = 1024;      // lanes of a coarse workgroup
+constexpr uint32_t SORT_SLAB = 4096;       // scalars per coarse workgroup (4 per lane): few, long-lived workgroups, so
+                                           // the 8-byte pieces of an output line meet in one L2 before the line is evicted
 constexpr uint32_t SORT_MAX_COARSE = 2048; // coarse bins (LDS counters)
 constexpr uint32_t SORT_MAX_LOW = 11;      // low bits sorted by the fine pass (2048 LDS counters)
 
@@ -77,14 +79,14 @@ __device__ __forceinline__ uint32_t digit_gid(int32_t d, uint32_t w, uint32_t sh
     return (shared ? 0u : w) * nbk + (uint32_t)(d < 0 ? -d : d) - 1u;
 }
 
-__global__ __launch_bounds__(256) void msm_coarse_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
+__global__ __launch_bounds__(SORT_LANES) void msm_coarse_hist_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
                                                                uint32_t W, uint32_t nbk, uint32_t shared, uint32_t low_bits,
                                                                uint32_t n_coarse, uint32_t* __restrict__ wg_counts) {
     __shared__ uint32_t h[SORT_MAX_COARSE];
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) h[k] = 0;
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) h[k] = 0;
     __syncthreads();
-    for (uint32_t r = 0; r < SORT_SLAB / 256; ++r) {
-        const uint32_t i = blockIdx.x * SORT_SLAB + r * 256 + threadIdx.x;
+    for (uint32_t r = 0; r < SORT_SLAB / SORT_LANES; ++r) {
+        const uint32_t i = blockIdx.x * SORT_SLAB + r * SORT_LANES + threadIdx.x;
         if (i >= n) break;
         DigitIter it(ld(scalars + i), c);
         for (uint32_t w = 0; w < W; ++w) {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void msm_coarse_hist_kernel(const fr_t* __rest
         }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) wg_counts[(size_t)k * gridDim.x + blockIdx.x] = h[k];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) wg_counts[(size_t)k * gridDim.x + blockIdx.x] = h[k];
 }
 
 // ---- exclusive scan of a vector in tiles of SCAN_TILE entries:
@@ -167,17 +169,17 @@ __global__ __launch_bounds__(256) void msm_scan_kernel(const uint32_t* __restric
 }
 
 // coarse scatter: wg_offsets is the exclusive scan of wg_counts (bin-major)
-__global__ __launch_bounds__(256) void msm_coarse_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
+__global__ __launch_bounds__(SORT_LANES) void msm_coarse_scatter_kernel(const fr_t* __restrict__ scalars, uint32_t n, uint32_t c,
                                                                   uint32_t W, uint32_t nbk, uint32_t shared,
                                                                   uint32_t level_stride, uint32_t low_bits, uint32_t n_coarse,
                                                                   const uint32_t* __restrict__ wg_offsets,
                                                                   uint2* __restrict__ coarse) {
     __shared__ uint32_t cur[SORT_MAX_COARSE];
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += 256) cur[k] = wg_offsets[(size_t)k * gridDim.x + blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) cur[k] = wg_offsets[(size_t)k * gridDim.x + blockIdx.x];
     __syncthreads();
     const uint32_t low_mask = (1u << low_bits) - 1u;
-    for (uint32_t r = 0; r < SORT_SLAB / 256; ++r) {
-        const uint32_t i = blockIdx.x * SORT_SLAB + r * 256 + threadIdx.x;
+    for (uint32_t r = 0; r < SORT_SLAB / SORT_LANES; ++r) {
+        const uint32_t i = blockIdx.x * SORT_SLAB + r * SORT_LANES + threadIdx.x;
         if (i >= n) break;
         DigitIter it(ld(scalars + i), c);
         for (uint32_t w = 0; w < W; ++w) {
@@ -232,13 +234,17 @@ __global__ __launch_bounds__(1024) void msm_fine_hist_kernel(const uint2* __rest
 
 __global__ __launch_bounds__(1024) void msm_fine_scatter_kernel(const uint2* __restrict__ coarse,
                                                                  const uint32_t* __restrict__ wg_offsets, uint32_t num_wg,
-                                                                 uint32_t low_bits, uint32_t total_buckets,
+                                                                 uint32_t n_bins, uint32_t low_bits, uint32_t total_buckets,
                                                                  const uint32_t* __restrict__ part_hist,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                                  uint32_t* __restrict__ sorted) {
     __shared__ uint32_t h[1u << SORT_MAX_LOW];
     __shared__ uint32_t part_sum[1024];
-    const uint32_t bin = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    // workgroup ids go round the 8 XCDs: the parts of one bin take ids 8 apart, so they run at about
+    // the same time on ONE XCD and their 4-byte stores into the bin's output meet in that L2
+    const uint32_t group = blockIdx.x / (8 * FINE_MAX_PARTS), r = blockIdx.x % (8 * FINE_MAX_PARTS);
+    const uint32_t bin = group * 8 + (r & 7u), part = r >> 3, tid = threadIdx.x;
+    if (bin >= n_bins) return;
     const FinePart f = fine_part(wg_offsets, num_wg, bin, part);
     if (part >= f.parts) return;
     const uint32_t nlow = 1u << low_bits;
@@ -794,17 +800,17 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[0], st));
     HIP_CHECK(hipMemsetAsync(s.wg_counts.p + (matrix - 1), 0, sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
+    hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(SORT_LANES), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
                        n_coarse, s.wg_counts.p);
     hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p);
     hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(1024), 0, st, s.tile_sums.p, tiles);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p, s.wg_offsets.p);
-    hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(256), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
+    hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(SORT_LANES), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
                        (uint32_t)pts.level_stride, low_bits, n_coarse, s.wg_offsets.p, s.coarse.p);
     hipLaunchKernelGGL(msm_fine_hist_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p, s.wg_offsets.p,
                        num_wg, low_bits, s.part_hist.p);
-    hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p,
-                       s.wg_offsets.p, num_wg, low_bits, total_buckets, s.part_hist.p, s.counts.p, s.offsets.p, s.sorted.p);
+    hipLaunchKernelGGL(msm_fine_scatter_kernel, dim3(((n_coarse + 7) / 8) * 8 * FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p,
+                       s.wg_offsets.p, num_wg, n_coarse, low_bits, total_buckets, s.part_hist.p, s.counts.p, s.offsets.p, s.sorted.p);
     const uint32_t oblk = (total_buckets + 256 * ORDER_PER_LANE - 1) / (256 * ORDER_PER_LANE);
     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(oblk), dim3(256), 0, st, s.counts.p, total_buckets, classes, s.bins.p);
     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(1), dim3(256), 0, st, s.bins.p, n_big);
