@@ -10,7 +10,7 @@ import pytest
 
 from conftest import golden
 from oracle import cref, curve, fft as offt, protocol as P
-from oracle.field import R_MOD, root_of_unity, fr_to_bytes
+from oracle.field import R_MOD, root_of_unity, fr_to_bytes, fr_inv
 
 pytestmark = pytest.mark.gpu
 
@@ -231,6 +231,39 @@ def test_msm_full_size_trapdoor(ctx):
         out = pa._lib.G1()
         ctx.check(pa._lib.lib.plonk_commit(ctx.h, srs.h, sc.ctypes.data_as(C.c_void_p), n, C.byref(out)))
         assert pa.api._g1_value(out) == curve.to_affine(curve.scalar_mul(G, P.poly_eval(vals, tau))), kind
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_msm_largest_sizes_closed_form(ctx, log_n):
+    """2^22 and 2^24 points (the size of the largest configuration's SRS), scalars too many to
+    evaluate on the host: the NTT of the unit vector e_j is the geometric sequence w^(j k) -- full-width,
+    uniform-looking scalars -- and its commitment has the closed form
+    sum_k (w^j tau)^k * G = (tau^n - 1) / (w^j tau - 1) * G."""
+    import plonk_amd as pa
+    n = 1 << log_n
+    tau = P.synthetic_tau(log_n)
+    srs = pa.Srs.from_tau(tau, n - 1)
+    j = 0x2F3A5 % n | 1
+    e = np.zeros((n, 4), dtype=np.uint64)
+    e[j] = pa.fr_to_array([1])[0]
+    dev = ctx.alloc(n * 32)
+    try:
+        ctx.upload(dev, e)
+        del e
+        ctx.ntt_dev(dev, log_n, 0)
+        got = srs.commit_dev(dev, n)
+        # a prefix as well: the closed form of a partial geometric sum
+        m = n - 12345
+        got_m = srs.commit_dev(dev, m)
+    finally:
+        ctx.free(dev)
+    wj = pow(offt.Domain(n).omega, j, R_MOD)
+    q = wj * tau % R_MOD
+    G = curve.G1_GEN
+    full = (pow(tau, n, R_MOD) - 1) * fr_inv((q - 1) % R_MOD) % R_MOD
+    part = (pow(q, m, R_MOD) - 1) * fr_inv((q - 1) % R_MOD) % R_MOD
+    assert got == curve.to_affine(curve.scalar_mul(G, full))
+    assert got_m == curve.to_affine(curve.scalar_mul(G, part))
 
 
 # ------------------------------------------------------------------ quotient + prover
