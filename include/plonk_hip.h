@@ -174,9 +174,10 @@ uint32_t plonk_msm_window_bits(size_t n);
 
 /* Device-time breakdown of the last timed plonk_commit / plonk_commit_dev on this context
  * (measurement aid, no counterpart in the reference): the sort of the (point, sign) entries by
- * bucket, the accumulation of oversized buckets (one workgroup each), the bucket accumulation
- * kernel proper (one lane per bucket), and the reduction of the bucket sums including the copy of
- * the result to the host; `entries` = number of mixed additions the bucket kernels performed. */
+ * bucket, the bucket accumulation kernel proper (one lane per bucket), the accumulation of
+ * oversized buckets that follows it (one workgroup each), and the reduction of the bucket sums
+ * including the copy of the result to the host; `entries` = number of mixed additions the bucket
+ * kernels performed. */
 typedef struct plonk_msm_timing {
     float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;
     uint64_t entries;

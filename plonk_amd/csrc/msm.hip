@@ -668,7 +668,7 @@ static host::G1XyzzH xyzz_to_host(const g1_xyzz_t& d) {
 // tail of MSM k-1 run underneath the bucket accumulation of MSM k.
 struct MsmSlot {
     hipEvent_t sorted_ev = nullptr, buckets_ev = nullptr, done_ev = nullptr;   // order the phases
-    hipEvent_t t_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // timing marks (only when enabled)
+    hipEvent_t t_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // timing marks (only when enabled)
     bool timed = false;
     uint32_t* host_entries = nullptr;   // pinned: (point, sign) entries of the last run
     DevBuf<uint32_t> sorted, counts, offsets, wg_counts, wg_offsets, tile_sums, part_hist, order, bins;
@@ -824,10 +824,6 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     // ---- bucket phase ----
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
-    hipLaunchKernelGGL(msm_huge_bucket_kernel, dim3(HUGE_PIECES, 16), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
-                       s.counts.p, s.order.p, n_big, max_huge, s.pieces.p);
-    hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                       s.order.p, n_big, max_huge, s.pieces.p, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[2], st));
     // lanes per bucket: a small bucket set with long buckets is spread over more lanes
     uint32_t log_lpb = 0;
@@ -846,6 +842,14 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
         hipLaunchKernelGGL(msm_bucket_split_kernel<3>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
                            s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[3], st));
+    // The oversized buckets come AFTER the lane-per-bucket kernel (they write other buckets, so the
+    // order is free): two nearly empty launches ahead of it would each have to drain through a chip
+    // that the previous MSM's reduction is using, and hold the big kernel back by that long.
+    hipLaunchKernelGGL(msm_huge_bucket_kernel, dim3(HUGE_PIECES, 16), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                       s.counts.p, s.order.p, n_big, max_huge, s.pieces.p);
+    hipLaunchKernelGGL(msm_big_bucket_kernel, dim3(512), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
+                       s.order.p, n_big, max_huge, s.pieces.p, s.buckets.p);
+    if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[5], st));
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
     return;
     }
@@ -948,9 +952,9 @@ void msm_last_timing(Ctx* ctx, MsmTiming* out) {
     PLONK_REQUIRE(!s.empty && s.c != 0 && s.timed, "msm timing: no timed MSM has run on this context");
     HIP_CHECK(hipEventSynchronize(s.t_ev[4]));
     HIP_CHECK(hipEventElapsedTime(&out->sort_ms, s.t_ev[0], s.t_ev[1]));
-    HIP_CHECK(hipEventElapsedTime(&out->big_bucket_ms, s.t_ev[1], s.t_ev[2]));
     HIP_CHECK(hipEventElapsedTime(&out->bucket_ms, s.t_ev[2], s.t_ev[3]));
-    HIP_CHECK(hipEventElapsedTime(&out->reduce_ms, s.t_ev[3], s.t_ev[4]));
+    HIP_CHECK(hipEventElapsedTime(&out->big_bucket_ms, s.t_ev[3], s.t_ev[5]));
+    HIP_CHECK(hipEventElapsedTime(&out->reduce_ms, s.t_ev[5], s.t_ev[4]));
     out->entries = *s.host_entries;
     out->window_bits = s.c;
     out->bucket_sets = s.W;
