@@ -131,6 +131,110 @@ __device__ __forceinline__ void ptx_add(PtX& acc, const PtX& q) {
     acc.zzz = M::mul(M::mul(acc.zzz, q.zzz), PPP);
 }
 
+// ---- one addition by a PAIR of neighbouring lanes (even, odd) ----
+// The reductions after the bucket phase are chains of dependent additions run by a handful of waves,
+// so what counts there is the length of one addition's instruction stream, not the work.  A pair
+// holds a point as
+//     even lane: p = X, s = ZZ,  t = ZZZ          odd lane: p = Y, s = ZZZ, t = ZZ
+// and both lanes run ONE instruction stream whose products differ by lane:
+//     m1 = (U1 | S1), m2 = (U2 | S2), m3 = (ZZZ1 ZZZ2 | ZZ1 ZZ2), D = (P | R), D^2 = (PP | RR),
+//     (PPP | ZZ3), (Q | -), then (ZZZ3 | Y3) as one a b - c d (c = 0 on the even lane):
+// 7 products deep instead of 14, with values handed across by quad-permute moves.
+struct PairPt {
+    fqx p, s, t;
+};
+
+template <int CTRL>
+__device__ __forceinline__ fqx pair_bcast(const fqx& a) {   // CTRL 0xA0: from the even lane; 0xF5: from the odd lane
+    fqx r;
+#pragma unroll
+    for (int k = 0; k < FqX::L; ++k) r.l[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[k], CTRL, 0xf, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ fqx pair_sel(bool odd, const fqx& if_odd, const fqx& if_even) {
+    fqx r;
+#pragma unroll
+    for (int k = 0; k < FqX::L; ++k) r.l[k] = odd ? if_odd.l[k] : if_even.l[k];
+    return r;
+}
+// ZZ of a pair-held point, on either lane (all-zero limbs mark the identity)
+__device__ __forceinline__ bool pair_is_inf(const PairPt& a, bool odd) { return x_limbs_zero<FqX>(odd ? a.t : a.s); }
+
+__device__ __forceinline__ PairPt pair_from_ptx(const PtX& r, bool odd) {
+    PairPt a;
+    a.p = pair_sel(odd, r.y, r.x);
+    a.s = pair_sel(odd, r.zzz, r.zz);
+    a.t = pair_sel(odd, r.zz, r.zzz);
+    return a;
+}
+__device__ __forceinline__ PtX pair_to_ptx(const PairPt& a, bool odd) {   // the whole point, on both lanes
+    PtX r;
+    r.x = pair_bcast<0xA0>(a.p);
+    r.y = pair_bcast<0xF5>(a.p);
+    r.zz = pair_bcast<0xA0>(a.s);
+    r.zzz = pair_bcast<0xA0>(a.t);
+    return r;
+}
+
+// a += b; both lanes of a pair must call it together (same control flow on both)
+__device__ __forceinline__ void pair_add(PairPt& a, const PairPt& b, bool odd) {
+    if (pair_is_inf(b, odd)) return;
+    if (pair_is_inf(a, odd)) {
+        a = b;
+        return;
+    }
+    const fqx m1 = qmul(a.p, b.s);                     // U1 = X1 ZZ2     | S1 = Y1 ZZZ2
+    const fqx m2 = qmul(b.p, a.s);                     // U2 = X2 ZZ1     | S2 = Y2 ZZZ1
+    const fqx m3 = qmul(a.t, b.t);                     // ZZZ1 ZZZ2       | ZZ1 ZZ2
+    const fqx D = x_sub<FqX, 2>(m2, m1);               // P               | R        (< 4p)
+    const int dz = x_is_zero16<FqX>(D) ? 1 : 0;
+    const int pz = __builtin_amdgcn_mov_dpp(dz, 0xA0, 0xf, 0xf, true);
+    if (pz) {                                          // P = 0: the same or opposite points -- whole-point routine
+        PtX fa = pair_to_ptx(a, odd);
+        const PtX fb = pair_to_ptx(b, odd);
+        ptx_add<MulInline>(fa, fb);
+        a = pair_from_ptx(fa, odd);
+        return;
+    }
+    const fqx sq = qsqr(D);                            // PP              | RR
+    const fqx PP = pair_bcast<0xA0>(sq);
+    const fqx n1 = qmul(pair_sel(odd, m3, D), PP);     // PPP = P PP      | ZZ3 = ZZ1 ZZ2 PP
+    const fqx n2 = qmul(m1, PP);                       // Q = U1 PP       | (unused)
+    const fqx PPP = pair_bcast<0xA0>(n1);
+    const fqx Q = pair_bcast<0xA0>(n2);
+    const fqx X3 = x_sub_sub2<FqX, 6>(sq, PPP, Q);     // (unused)        | RR - PPP - 2Q  (< 8p)
+    const fqx Dd = x_sub<FqX, 8>(Q, X3);               // (unused)        | Q - X3
+    // ZZZ3 = ZZZ1 ZZZ2 PPP (c = 0)                    | Y3 = R (Q - X3) - S1 PPP
+    const fqx v = MulInline::mul_sub(pair_sel(odd, D, m3), pair_sel(odd, Dd, n1), pair_sel(odd, m1, x_zero<FqX>()), PPP);
+    const fqx X3e = pair_bcast<0xF5>(X3), ZZ3e = pair_bcast<0xF5>(n1), ZZZ3o = pair_bcast<0xA0>(v);
+    a.p = pair_sel(odd, v, X3e);
+    a.s = pair_sel(odd, ZZZ3o, ZZ3e);
+    a.t = pair_sel(odd, n1, v);
+}
+
+// a point in memory as four coordinate slots
+__device__ __forceinline__ PairPt ld_pair(const g1x_xyzz_t* q, bool odd) {
+    PairPt a;
+    a.p = ldx(odd ? &q->y : &q->x);
+    a.s = ldx(odd ? &q->zzz : &q->zz);
+    a.t = ldx(odd ? &q->zz : &q->zzz);
+    return a;
+}
+__device__ __forceinline__ void st_pair(g1x_xyzz_t* q, const PairPt& a, bool odd) {
+    if (odd) {
+        stx(&q->y, a.p);
+    } else {
+        stx(&q->x, a.p);
+        stx(&q->zz, a.s);
+        stx(&q->zzz, a.t);
+    }
+}
+__device__ __forceinline__ PairPt pair_identity() {
+    PairPt a;
+    a.p = x_zero<FqX>(); a.s = x_zero<FqX>(); a.t = x_zero<FqX>();
+    return a;
+}
+
 __device__ __forceinline__ AffX ld_affx(const g1x_affine_t* p) {
     AffX r;
     r.x = ldx(&p->x);

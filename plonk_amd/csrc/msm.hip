@@ -554,35 +554,42 @@ __device__ __forceinline__ void block_sum(PtX& acc, g1x_xyzz_t* red, uint32_t ti
 // share, then the lanes' sums are folded through LDS.  Both phases go through ONE expansion of the
 // point addition: in these short kernels most of the time is the first pass over its ~55 KB of
 // straight-line code, so a second copy would nearly double the run time.  Result in lane 0.
+// Every addition is run by a pair of lanes (pair_add): LANES lanes are LANES / 2 pairs.  Result in
+// pair 0 (lanes 0 and 1).
 template <uint32_t LANES, class Index>
-__device__ __forceinline__ PtX reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
-                                             g1x_xyzz_t* red, uint32_t tid) {
-    const uint32_t n_serial = (count + LANES - 1) / LANES;
+__device__ __forceinline__ PairPt reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
+                                                g1x_xyzz_t* red, uint32_t tid) {
+    constexpr uint32_t PAIRS = LANES / 2;
+    const uint32_t pid = tid >> 1;
+    const bool odd = (tid & 1u) != 0;
+    const uint32_t n_serial = (count + PAIRS - 1) / PAIRS;
     uint32_t levels = 0;
-    while ((1u << levels) < LANES) ++levels;
-    PtX acc = ptx_identity();
+    while ((1u << levels) < PAIRS) ++levels;
+    PairPt acc = pair_identity();
 #pragma unroll 1
     for (uint32_t step = 0; step < n_serial + levels; ++step) {
-        PtX o = ptx_identity();
+        PairPt o = pair_identity();
         if (step < n_serial) {
-            const uint32_t k = tid + step * LANES;
-            if (k < count) o = ld_ptx(src + index(k));
+            const uint32_t k = pid + step * PAIRS;
+            if (k < count) o = ld_pair(src + index(k), odd);
         } else {
-            const uint32_t half = LANES >> (step - n_serial + 1);
-            st_ptx(&red[tid], acc);
+            const uint32_t half = PAIRS >> (step - n_serial + 1);
+            st_pair(&red[pid], acc, odd);
             __syncthreads();
-            if (tid < half) o = ld_ptx(&red[tid + half]);
+            if (pid < half) o = ld_pair(&red[pid + half], odd);
             __syncthreads();
         }
-        ptx_add<MulInline>(acc, o);   // adding the identity returns at once
+        pair_add(acc, o, odd);   // adding the identity returns at once
     }
     return acc;
 }
 
-__global__ __launch_bounds__(64) void msm_rowcol_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
-                                                         uint32_t m, uint32_t ml, g1x_xyzz_t* __restrict__ row,
-                                                         g1x_xyzz_t* __restrict__ arow, g1x_xyzz_t* __restrict__ col) {
-    __shared__ g1x_xyzz_t red[64];
+constexpr uint32_t ROWCOL_LANES = 128, MASKED_LANES = 512;
+
+__global__ __launch_bounds__(ROWCOL_LANES) void msm_rowcol_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
+                                                                   uint32_t m, uint32_t ml, g1x_xyzz_t* __restrict__ row,
+                                                                   g1x_xyzz_t* __restrict__ arow, g1x_xyzz_t* __restrict__ col) {
+    __shared__ g1x_xyzz_t red[ROWCOL_LANES / 2];
     const uint32_t rows = 1u << (m - ml), cols = 1u << ml, chunks = 1u << m;
     const uint32_t w = blockIdx.y, tid = threadIdx.x;
     uint32_t job = blockIdx.x;
@@ -601,14 +608,14 @@ __global__ __launch_bounds__(64) void msm_rowcol_kernel(const g1x_xyzz_t* __rest
         dst = col + (size_t)w * cols + job;
         first = job; stride = cols; count = rows;
     }
-    const PtX acc = reduce_points<64>(src, count, [=](uint32_t k) { return first + (size_t)k * stride; }, red, tid);
-    if (tid == 0) st_ptx(dst, acc);
+    const PairPt acc = reduce_points<ROWCOL_LANES>(src, count, [=](uint32_t k) { return first + (size_t)k * stride; }, red, tid);
+    if (tid < 2) st_pair(dst, acc, tid == 1);
 }
 
-__global__ __launch_bounds__(256) void msm_masked_kernel(const g1x_xyzz_t* __restrict__ row, const g1x_xyzz_t* __restrict__ arow,
-                                                          const g1x_xyzz_t* __restrict__ col, uint32_t m, uint32_t ml,
-                                                          g1_xyzz_t* __restrict__ out) {
-    __shared__ g1x_xyzz_t red[256];
+__global__ __launch_bounds__(MASKED_LANES) void msm_masked_kernel(const g1x_xyzz_t* __restrict__ row, const g1x_xyzz_t* __restrict__ arow,
+                                                                   const g1x_xyzz_t* __restrict__ col, uint32_t m, uint32_t ml,
+                                                                   g1_xyzz_t* __restrict__ out) {
+    __shared__ g1x_xyzz_t red[MASKED_LANES / 2];
     const uint32_t rows = 1u << (m - ml), cols = 1u << ml;
     const uint32_t q = blockIdx.x, nq = gridDim.x, w = blockIdx.y, tid = threadIdx.x;
     const g1x_xyzz_t* src;
@@ -621,13 +628,19 @@ __global__ __launch_bounds__(256) void msm_masked_kernel(const g1x_xyzz_t* __res
         src = row + (size_t)w * rows; count = rows >> 1; bit = q - 1 - ml;
     }
     // q > 0: the k-th index with bit `bit` set
-    const PtX acc = reduce_points<256>(src, count, [=](uint32_t k) -> size_t {
+    const PairPt acc = reduce_points<MASKED_LANES>(src, count, [=](uint32_t k) -> size_t {
         return q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
     }, red, tid);
-    if (tid != 0) return;
-    g1_xyzz_t r;   // back to the saturated form for the host
-    r.x = x_to_sat<FqX>(acc.x); r.y = x_to_sat<FqX>(acc.y); r.zz = x_to_sat<FqX>(acc.zz); r.zzz = x_to_sat<FqX>(acc.zzz);
-    st_xyzz(out + (size_t)w * nq + q, r);
+    if (tid >= 2) return;
+    // back to the saturated form for the host: lane 0 holds X, ZZ, ZZZ, lane 1 holds Y
+    g1_xyzz_t* dst = out + (size_t)w * nq + q;
+    if (tid == 1) {
+        st(&dst->y, x_to_sat<FqX>(acc.p));
+    } else {
+        st(&dst->x, x_to_sat<FqX>(acc.p));
+        st(&dst->zz, x_to_sat<FqX>(acc.s));
+        st(&dst->zzz, x_to_sat<FqX>(acc.t));
+    }
 }
 
 // saturated affine -> x-form affine
@@ -858,9 +871,9 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
     hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunk_log, chunks,
                        total_chunks, s.A.p, s.R.p);
-    hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(64), 0, st, s.A.p, s.R.p, log_chunks, ml, s.row.p,
+    hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(ROWCOL_LANES), 0, st, s.A.p, s.R.p, log_chunks, ml, s.row.p,
                        s.arow.p, s.col.p);
-    hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(256), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, s.sums.p);
+    hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(MASKED_LANES), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, s.sums.p);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)S * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[4], st));
