@@ -36,7 +36,8 @@ struct BucketClasses {
     uint32_t big, huge, shift;
 };
 static constexpr uint32_t CHUNK_LOG_BIG = 3;    // log2 of the buckets per lane in the running-sum step ...
-static constexpr uint32_t CHUNK_LOG_SMALL = 1;  // ... and for small bucket sets, where only the depth of the reduction counts
+static constexpr uint32_t CHUNK_LOG_SMALL = 0;  // ... none for small bucket sets, where only the depth of the reduction counts:
+                                                //     the buckets themselves are the chunks (A_t = R_t = B_{t+1})
 
 // signed c-bit digits of a canonical scalar, least significant window first
 struct DigitIter {
@@ -869,9 +870,14 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     // ---- tail phase, on the ctx stream (idle while its commitments are in flight) ----
     st = ctx->stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
-    hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunk_log, chunks,
-                       total_chunks, s.A.p, s.R.p);
-    hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(ROWCOL_LANES), 0, st, s.A.p, s.R.p, log_chunks, ml, s.row.p,
+    const g1x_xyzz_t *chunk_a = s.buckets.p, *chunk_r = s.buckets.p;
+    if (chunk_log != 0) {
+        hipLaunchKernelGGL(msm_chunk_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, st, s.buckets.p, nbk, chunk_log, chunks,
+                           total_chunks, s.A.p, s.R.p);
+        chunk_a = s.A.p;
+        chunk_r = s.R.p;
+    }
+    hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(ROWCOL_LANES), 0, st, chunk_a, chunk_r, log_chunks, ml, s.row.p,
                        s.arow.p, s.col.p);
     hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(MASKED_LANES), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, s.sums.p);
     HIP_CHECK(hipGetLastError());
