@@ -426,6 +426,45 @@ __global__ __launch_bounds__(256) void msm_bucket_split_kernel(const g1x_affine_
     if (live && sub == 0) st_ptx(buckets + gid, acc);
 }
 
+// ---- 5a''. for the smallest inputs even that is a few long dependent chains per SIMD.  Here a PAIR of lanes runs each addition
+//          (pair_madd: half the instruction stream), 2^LOG_PPB pairs share a bucket (entries
+//          k = sub, sub + PPB, ...) and fold their sums through LDS ----
+template <uint32_t LOG_PPB>
+__global__ __launch_bounds__(256) void msm_bucket_pair_kernel(const g1x_affine_t* __restrict__ points,
+                                                               const uint32_t* __restrict__ sorted,
+                                                               const uint32_t* __restrict__ offsets,
+                                                               const uint32_t* __restrict__ counts,
+                                                               uint32_t total_buckets, const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ n_big,
+                                                               g1x_xyzz_t* __restrict__ buckets) {
+    constexpr uint32_t PPB = 1u << LOG_PPB;
+    __shared__ g1x_xyzz_t red[128];
+    const uint32_t tid = threadIdx.x, pid = tid >> 1, sub = pid & (PPB - 1);
+    const bool odd = (tid & 1u) != 0;
+    const uint32_t slot = ((blockIdx.x * 128 + pid) >> LOG_PPB) + n_big[0];
+    const bool live = slot < total_buckets;
+    const uint32_t gid = live ? order[slot] : 0u;
+    const uint32_t cnt = live ? counts[gid] : 0u;
+    const uint32_t* src = sorted + (live ? offsets[gid] : 0u);
+    PairPt acc = pair_identity();
+    for (uint32_t k = sub; k < cnt; k += PPB) {
+        const uint32_t e = src[k];
+        const g1x_affine_t* pt = points + (e & ~SIGN_BIT);
+        const fqx c = ldx(odd ? &pt->y : &pt->x);
+        pair_madd(acc, c, entry_neg(e), odd);
+    }
+#pragma unroll 1
+    for (uint32_t half = PPB >> 1; half > 0; half >>= 1) {
+        st_pair(&red[pid], acc, odd);
+        __syncthreads();
+        PairPt o = pair_identity();
+        if (sub < half) o = ld_pair(&red[pid + half], odd);
+        __syncthreads();
+        pair_add(acc, o, odd);
+    }
+    if (live && sub == 0) st_pair(buckets + gid, acc, odd);
+}
+
 // sum over the workgroup of the lanes' points, result in lane 0's acc
 __device__ __forceinline__ void block_sum_256(PtX& acc, g1x_xyzz_t* red, uint32_t tid) {
     st_ptx(&red[tid], acc);
@@ -839,22 +878,37 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[2], st));
-    // lanes per bucket: a small bucket set with long buckets is spread over more lanes
-    uint32_t log_lpb = 0;
-    while (log_lpb < 3 && (total_buckets << log_lpb) < (1u << 17) && (mean >> log_lpb) >= 16) ++log_lpb;
-    const uint32_t sblk = (uint32_t)((((size_t)total_buckets << log_lpb) + 255) / 256);
-    if (log_lpb == 0)
-        hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
-                           total_buckets, s.order.p, n_big, s.buckets.p);
-    else if (log_lpb == 1)
-        hipLaunchKernelGGL(msm_bucket_split_kernel<1>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
-                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
-    else if (log_lpb == 2)
-        hipLaunchKernelGGL(msm_bucket_split_kernel<2>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
-                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
-    else
-        hipLaunchKernelGGL(msm_bucket_split_kernel<3>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
-                           s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+    if (total_buckets < (1u << 17) && (size_t)W * n <= ((size_t)1 << 19)) {
+        // few entries: all latency.  Pairs per bucket: up to 2^18 lanes in all, at least ~4 additions per pair
+        uint32_t log_ppb = 0;
+        while (log_ppb < 3 && (total_buckets << (log_ppb + 2)) <= (1u << 18) && (mean >> (log_ppb + 1)) >= 4) ++log_ppb;
+        const uint32_t pblk = (uint32_t)((((size_t)total_buckets << log_ppb) + 127) / 128);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(pblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p, total_buckets,
+                               s.order.p, n_big, s.buckets.p);
+        };
+        if (log_ppb == 0) launch(msm_bucket_pair_kernel<0>);
+        else if (log_ppb == 1) launch(msm_bucket_pair_kernel<1>);
+        else if (log_ppb == 2) launch(msm_bucket_pair_kernel<2>);
+        else launch(msm_bucket_pair_kernel<3>);
+    } else {
+        // lanes per bucket: a small bucket set with long buckets is spread over more lanes
+        uint32_t log_lpb = 0;
+        while (log_lpb < 3 && (total_buckets << log_lpb) < (1u << 17) && (mean >> log_lpb) >= 16) ++log_lpb;
+        const uint32_t sblk = (uint32_t)((((size_t)total_buckets << log_lpb) + 255) / 256);
+        if (log_lpb == 0)
+            hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
+                               total_buckets, s.order.p, n_big, s.buckets.p);
+        else if (log_lpb == 1)
+            hipLaunchKernelGGL(msm_bucket_split_kernel<1>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                               s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+        else if (log_lpb == 2)
+            hipLaunchKernelGGL(msm_bucket_split_kernel<2>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                               s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+        else
+            hipLaunchKernelGGL(msm_bucket_split_kernel<3>, dim3(sblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p,
+                               s.counts.p, total_buckets, s.order.p, n_big, s.buckets.p);
+    }
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[3], st));
     // The oversized buckets come AFTER the lane-per-bucket kernel (they write other buckets, so the
     // order is free): two nearly empty launches ahead of it would each have to drain through a chip
