@@ -12,7 +12,7 @@
 //   4. reduce   : sum_b b * B_b: lanes take chunks of L buckets (running sums A_t, R_t), then
 //                 sum A_t and the bit-masked sums of R_t by LDS trees (sum_t t R_t = sum_i 2^i G_i).
 //   5. the few resulting points are combined and normalised on the host: O(100) point operations.
-// An SRS of >= 2^10 points carries a table of its points times 2^(c w): all windows then share ONE
+// An SRS of >= 16 points carries a table of its points times 2^(c w): all windows then share ONE
 // bucket set, so steps 3-4 run over 2^(c-1) buckets once instead of once per window.
 // Integer VALU work throughout; bytes moved are negligible next to the field multiplications.
 #include <algorithm>
@@ -781,8 +781,8 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
 static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts, const fr_t* scalars, size_t n,
                         bool tail_phase) {
     const g1x_affine_t* points = pts.px;
-    // the table pays once the shared bucket set (2^(table_c-1) buckets) is reasonably full
-    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 6)) != 0) ? 1u : 0u;
+    // the shared bucket set is used unless the input is a sliver of the SRS (n < 2^(table_c - 12))
+    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 12)) != 0) ? 1u : 0u;
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
     if (n == 0) return;

@@ -28,7 +28,7 @@ struct MsmPoints {
 inline MsmPoints msm_points(const Srs* s) { return MsmPoints{s->px.p, s->n, s->table_c}; }
 
 // SRS sizes from which the window table is built (below it the per-window bucket sets are cheap).
-constexpr size_t MSM_TABLE_MIN_POINTS = (size_t)1 << 10;
+constexpr size_t MSM_TABLE_MIN_POINTS = (size_t)1 << 4;
 
 uint32_t msm_window_bits(size_t n);
 uint32_t msm_table_bits(size_t n);
