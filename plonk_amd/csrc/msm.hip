@@ -782,7 +782,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
                         bool tail_phase) {
     const g1x_affine_t* points = pts.px;
     // the shared bucket set is used unless the input is a sliver of the SRS (n < 2^(table_c - 12))
-    const uint32_t shared = (pts.table_c && (n >> (pts.table_c - 12)) != 0) ? 1u : 0u;
+    const uint32_t shared = (pts.table_c && (n >> (pts.table_c > 12 ? pts.table_c - 12 : 0)) != 0) ? 1u : 0u;
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
     if (n == 0) return;
@@ -1090,12 +1090,13 @@ __global__ __launch_bounds__(256) void g1_shift_level_kernel(const g1_affine_t* 
 static void xyzz_to_affine(Ctx* ctx, const g1_xyzz_t* in, size_t n, fq_t* prefix, g1_affine_t* out);
 
 uint32_t msm_table_bits(size_t n) {
-    // 16 or 20: for both the top window of a 255-bit scalar is 15 bits wide, so no window crowds its
-    // digits into a handful of buckets.  ceil(256/c) is 13 for c = 20 and for c = 21, so a wider
-    // window would only add buckets; larger inputs put more points into each of the 2^19 buckets.
+    // 8, 13, 16 or 20: widths whose top window of a 255-bit scalar is still 7, 8, 15 and 15 bits wide, so
+    // no window crowds its digits into a handful of buckets.  The small widths keep the reduction of
+    // a small SRS shallow; ceil(256/c) is 13 for c = 20 and for c = 21, so a wider window would only
+    // add buckets, and larger inputs put more points into each of the 2^19 buckets.
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    return lg <= 17 ? 16u : 20u;
+    return lg <= 8 ? 8u : (lg <= 12 ? 13u : (lg <= 17 ? 16u : 20u));
 }
 
 // Builds srs->px as the window table [W][n]: row w holds 2^(c w) P_i in x-form.  With the table
