@@ -65,14 +65,16 @@ struct DigitIter {
 //          where `shared` mode has a single set (all windows feed ONE bucket set: the points of
 //          window w are then the precomputed 2^(c w) P_i of the SRS table) and otherwise window w
 //          is set w.  Two levels, both counting in LDS and never with global atomics:
-//            coarse: slabs of SORT_SLAB scalars; workgroup g counts its entries per coarse bin
+//            coarse: slabs of 4 scalars per lane; workgroup g counts its entries per coarse bin
 //                    (gid >> low_bits) into wg_counts[bin][g]; a scan of that matrix gives every
 //                    (bin, g) its own output run; the entries go there as (payload, gid low bits).
 //            fine:   one workgroup per coarse bin sorts its run by the low bits in LDS and emits
 //                    the per-bucket counts / offsets and the final entry list. ----
-constexpr uint32_t SORT_LANES = 1024;      // lanes of a coarse workgroup
-constexpr uint32_t SORT_SLAB = 4096;       // scalars per coarse workgroup (4 per lane): few, long-lived workgroups, so
-                                           // the 8-byte pieces of an output line meet in one L2 before the line is evicted
+constexpr uint32_t SORT_LANES = 1024;      // lanes of a coarse workgroup for large inputs, 4 scalars per lane: few, long-lived
+                                           // workgroups, so the 8-byte pieces of an output line meet in one L2 before the line
+                                           // is evicted.  Small inputs use 256-lane workgroups: they fit beside a bucket kernel
+                                           // that has left a CU half empty, where a 16-wave workgroup waits for it to drain.
+constexpr uint32_t SORT_PER_LANE = 4;
 constexpr uint32_t SORT_MAX_COARSE = 2048; // coarse bins (LDS counters)
 constexpr uint32_t SORT_MAX_LOW = 11;      // low bits sorted by the fine pass (2048 LDS counters)
 
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(SORT_LANES) void msm_coarse_hist_kernel(const fr_t*
                                                                uint32_t W, uint32_t nbk, uint32_t shared, uint32_t low_bits,
                                                                uint32_t n_coarse, uint32_t* __restrict__ wg_counts) {
     __shared__ uint32_t h[SORT_MAX_COARSE];
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) h[k] = 0;
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += blockDim.x) h[k] = 0;
     __syncthreads();
-    for (uint32_t r = 0; r < SORT_SLAB / SORT_LANES; ++r) {
-        const uint32_t i = blockIdx.x * SORT_SLAB + r * SORT_LANES + threadIdx.x;
+    for (uint32_t r = 0; r < SORT_PER_LANE; ++r) {
+        const uint32_t i = (blockIdx.x * SORT_PER_LANE + r) * blockDim.x + threadIdx.x;
         if (i >= n) break;
         DigitIter it(ld(scalars + i), c);
         for (uint32_t w = 0; w < W; ++w) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(SORT_LANES) void msm_coarse_hist_kernel(const fr_t*
         }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) wg_counts[(size_t)k * gridDim.x + blockIdx.x] = h[k];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += blockDim.x) wg_counts[(size_t)k * gridDim.x + blockIdx.x] = h[k];
 }
 
 // ---- exclusive scan of a vector in tiles of SCAN_TILE entries:
@@ -176,11 +178,11 @@ __global__ __launch_bounds__(SORT_LANES) void msm_coarse_scatter_kernel(const fr
                                                                   const uint32_t* __restrict__ wg_offsets,
                                                                   uint2* __restrict__ coarse) {
     __shared__ uint32_t cur[SORT_MAX_COARSE];
-    for (uint32_t k = threadIdx.x; k < n_coarse; k += SORT_LANES) cur[k] = wg_offsets[(size_t)k * gridDim.x + blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < n_coarse; k += blockDim.x) cur[k] = wg_offsets[(size_t)k * gridDim.x + blockIdx.x];
     __syncthreads();
     const uint32_t low_mask = (1u << low_bits) - 1u;
-    for (uint32_t r = 0; r < SORT_SLAB / SORT_LANES; ++r) {
-        const uint32_t i = blockIdx.x * SORT_SLAB + r * SORT_LANES + threadIdx.x;
+    for (uint32_t r = 0; r < SORT_PER_LANE; ++r) {
+        const uint32_t i = (blockIdx.x * SORT_PER_LANE + r) * blockDim.x + threadIdx.x;
         if (i >= n) break;
         DigitIter it(ld(scalars + i), c);
         for (uint32_t w = 0; w < W; ++w) {
@@ -807,7 +809,8 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     const uint32_t low_bits = std::min(SORT_MAX_LOW, std::max(2u, kbits > 9 ? kbits - 9 : 0u));
     const uint32_t n_coarse = (total_buckets + (1u << low_bits) - 1) >> low_bits;
     PLONK_REQUIRE(n_coarse <= SORT_MAX_COARSE, "msm: too many buckets for the sort");
-    const uint32_t num_wg = (uint32_t)((n + SORT_SLAB - 1) / SORT_SLAB);
+    const uint32_t sort_lanes = n < ((size_t)1 << 19) ? 256u : SORT_LANES, sort_slab = sort_lanes * SORT_PER_LANE;
+    const uint32_t num_wg = (uint32_t)((n + sort_slab - 1) / sort_slab);
     const uint32_t matrix = n_coarse * num_wg + 1;   // + the total
     const uint32_t tiles = (matrix + SCAN_TILE - 1) / SCAN_TILE;
     s.sorted.ensure((size_t)W * n);
@@ -853,12 +856,12 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[0], st));
     HIP_CHECK(hipMemsetAsync(s.wg_counts.p + (matrix - 1), 0, sizeof(uint32_t), st));
     HIP_CHECK(hipMemsetAsync(s.bins.p, 0, (ORDER_BINS + 4) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(SORT_LANES), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
+    hipLaunchKernelGGL(msm_coarse_hist_kernel, dim3(num_wg), dim3(sort_lanes), 0, st, scalars, (uint32_t)n, c, W, nbk, shared, low_bits,
                        n_coarse, s.wg_counts.p);
     hipLaunchKernelGGL(msm_scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p);
     hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(1024), 0, st, s.tile_sums.p, tiles);
     hipLaunchKernelGGL(msm_scan_kernel, dim3(tiles), dim3(256), 0, st, s.wg_counts.p, matrix, s.tile_sums.p, s.wg_offsets.p);
-    hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(SORT_LANES), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
+    hipLaunchKernelGGL(msm_coarse_scatter_kernel, dim3(num_wg), dim3(sort_lanes), 0, st, scalars, (uint32_t)n, c, W, nbk, shared,
                        (uint32_t)pts.level_stride, low_bits, n_coarse, s.wg_offsets.p, s.coarse.p);
     hipLaunchKernelGGL(msm_fine_hist_kernel, dim3(n_coarse, FINE_MAX_PARTS), dim3(1024), 0, st, s.coarse.p, s.wg_offsets.p,
                        num_wg, low_bits, s.part_hist.p);
