@@ -368,35 +368,24 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     // the wires' evaluations on the 4n coset (round 3 reads them; they depend on no challenge) are
     // computed while the last commitment's reduction drains
     const MsmFiller coset_abc = [&](hipStream_t s) { ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4); };
-    const auto blind_wire = [&](int k) {
+    // wire by wire: the device transforms and commits one wire while the next is prepared -- for a
+    // host witness the pageable upload keeps the host busy staging meanwhile
+    MsmBatch r1;
+    for (int k = 0; k < 3; ++k) {
+        if (evals_on_device) {
+            EV[k] = reinterpret_cast<const fr_t*>(evs[k]);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
+            EV[k] = ws->ev.p + k * n;
+        }
+        poly_copy(ctx, W[k], EV[k], n);
+        ntt_run(ctx, W[k], log_n, NTT_INVERSE, 1, 0);
         const fr_h b2[2] = {bl[2 * k + 1], bl[2 * k]};  // blind poly [b2, b1] (:205-207)
         poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
         poly_copy(ctx, CO[k], W[k], n + 2);
-    };
-    if (evals_on_device) {
-        for (int k = 0; k < 3; ++k) {
-            EV[k] = reinterpret_cast<const fr_t*>(evs[k]);
-            poly_copy(ctx, W[k], EV[k], n);
-        }
-        ntt_run(ctx, W[0], log_n, NTT_INVERSE, 3, n4);
-        for (int k = 0; k < 3; ++k) blind_wire(k);
-        const fr_t* cp[3] = {CO[0], CO[1], CO[2]};
-        const size_t cl[3] = {n + 2, n + 2, n + 2};
-        commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm, coset_abc);
-    } else {
-        // wire by wire: a pageable upload keeps the host busy staging, and meanwhile the device
-        // already transforms and commits the wire before
-        MsmBatch r1;
-        for (int k = 0; k < 3; ++k) {
-            HIP_CHECK(hipMemcpyAsync(ws->ev.p + k * n, evs[k], n * sizeof(fr_t), hipMemcpyHostToDevice, st));
-            EV[k] = ws->ev.p + k * n;
-            poly_copy(ctx, W[k], EV[k], n);
-            ntt_run(ctx, W[k], log_n, NTT_INVERSE, 1, 0);
-            blind_wire(k);
-            commit_add(ctx, srs, r1, CO[k], n + 2, ws->flag.p, shard);
-        }
-        commit_finish(ctx, r1, shard, comm, coset_abc);
+        commit_add(ctx, srs, r1, CO[k], n + 2, ws->flag.p, shard);
     }
+    commit_finish(ctx, r1, shard, comm, coset_abc);
     tr.absorb_g1("a_comm", comm[0]);
     tr.absorb_g1("b_comm", comm[1]);
     tr.absorb_g1("c_comm", comm[2]);
