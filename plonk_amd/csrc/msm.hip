@@ -571,33 +571,17 @@ __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __rest
     st_ptx(R + gid, running);
 }
 
-// sum of the 256 lanes' points through LDS; the result is in lane 0's acc
-__device__ __forceinline__ void block_sum(PtX& acc, g1x_xyzz_t* red, uint32_t tid, uint32_t lanes) {
-    st_ptx(&red[tid], acc);
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t s = lanes >> 1; s > 0; s >>= 1) {
-        if (tid < s) {
-            const PtX o = ld_ptx(&red[tid + s]);
-            ptx_add<MulInline>(acc, o);
-            st_ptx(&red[tid], acc);
-        }
-        __syncthreads();
-    }
-}
-
 // ---- 6b/6c. sum_t A_t and the bit-masked sums G_i = sum of R_t over the chunks t with bit i set (so
 //          that sum_t t R_t = sum_i 2^i G_i), through the view t = hi * 2^ml + lo of the chunk index:
 //          a low bit of t is a bit of lo, so its G_i is a masked sum of the 2^ml column sums
 //          Col_lo = sum_hi R[hi][lo]; a high bit is a bit of hi and goes through the row sums
 //          Row_hi = sum_lo R[hi][lo].  Two adds per chunk instead of one per chunk and bit.
-//          6b: one wave per row (R and A) or column; 6c: one workgroup per quantity. ----
-// Sum of `count` points src[index(k)] over a workgroup of LANES lanes: every lane first adds its
-// share, then the lanes' sums are folded through LDS.  Both phases go through ONE expansion of the
-// point addition: in these short kernels most of the time is the first pass over its ~55 KB of
-// straight-line code, so a second copy would nearly double the run time.  Result in lane 0.
-// Every addition is run by a pair of lanes (pair_add): LANES lanes are LANES / 2 pairs.  Result in
-// pair 0 (lanes 0 and 1).
+//          6b: one workgroup per row (R and A) or column; 6c: one workgroup per quantity. ----
+// Sum of `count` points src[index(k)] over a workgroup of LANES lanes = LANES / 2 pairs, every
+// addition run by a pair (pair_add): each pair first adds its share, then the pairs' sums are folded
+// through LDS.  Both phases go through ONE expansion of the addition: in these short kernels a good
+// part of the time is the first pass over its straight-line code, so a second copy would cost
+// nearly as much again.  Result in pair 0 (lanes 0 and 1).
 template <uint32_t LANES, class Index>
 __device__ __forceinline__ PairPt reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
                                                 g1x_xyzz_t* red, uint32_t tid) {
