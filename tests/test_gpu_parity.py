@@ -179,6 +179,29 @@ def test_srs_and_commit_trapdoor(ctx, n):
     assert pa.Commitment.commit([5] + [0] * n, srs).point == curve.to_affine(curve.scalar_mul(G, 5))  # normalised
 
 
+def test_commit_across_kernel_selection_boundaries(ctx):
+    """commit(f) = f(tau) * G at the SRS sizes where the window width (16, 2^9, 2^13, 2^18 points), the
+    bucket kernel (lane pairs up to 2^19 entries, several lanes per bucket, one lane per bucket) and
+    the reduction (with or without the running-sum stage) change, for uniform, tiny and sparse
+    coefficients and for polynomials shorter than the SRS."""
+    import plonk_amd as pa
+    rng = random.Random(77)
+    tau = 0x1F2E3D4C5B6A79887766554433221100FFEEDDCCBBAA9988 % R_MOD
+    for n in (15, 16, 17, 511, 512, 513, 8191, 8192, 8193, 20011, 40009, (1 << 17) - 5, (1 << 18) + 3):
+        srs = pa.Srs.from_tau(tau, n - 1)
+        for m in sorted({n, max(1, n // 3)}):
+            kind = rng.randrange(3)
+            if kind == 0:
+                f = [rng.randrange(R_MOD) for _ in range(m)]
+            elif kind == 1:
+                f = [rng.choice([0, 1, R_MOD - 1, 2, 5]) for _ in range(m)]
+            else:
+                f = [rng.randrange(R_MOD) if rng.random() < 0.3 else 0 for _ in range(m)]
+            want = curve.to_affine(curve.scalar_mul(curve.G1_GEN, P.poly_eval(f, tau)))
+            assert pa.Commitment.commit(f, srs).point == want, (n, m, kind)
+        srs.close()
+
+
 def test_srs_upload_roundtrip(ctx):
     import plonk_amd as pa
     o = P.Srs(777, 20)
