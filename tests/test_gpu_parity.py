@@ -344,7 +344,7 @@ def _public_input_circuit(k):
     return cs, pis
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "rp42_pi", "rp0", "synthetic6", "synthetic10", "pi_gates4", "pi_gates9"])
+@pytest.mark.parametrize("name", ["c1", "c2", "rp42_pi", "rp0", "synthetic6", "synthetic8", "synthetic10", "synthetic12", "pi_gates4", "pi_gates9"])
 def test_prove_matches_oracle_bytes(ctx, name):
     import plonk_amd as pa
     bl = _rand(98, 11)
