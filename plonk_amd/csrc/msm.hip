@@ -467,19 +467,27 @@ __global__ __launch_bounds__(256) void msm_bucket_pair_kernel(const g1x_affine_t
     if (live && sub == 0) st_pair(buckets + gid, acc, odd);
 }
 
-// sum over the workgroup of the lanes' points, result in lane 0's acc
-__device__ __forceinline__ void block_sum_256(PtX& acc, g1x_xyzz_t* red, uint32_t tid) {
+// Sum over the workgroup of the 256 lanes' points, folded by lane pairs (pair_add); the result is
+// written to *dst by lanes 0 and 1.
+__device__ __forceinline__ void block_sum_256(const PtX& acc, g1x_xyzz_t* red, uint32_t tid, g1x_xyzz_t* dst) {
+    const uint32_t pid = tid >> 1;
+    const bool odd = (tid & 1u) != 0;
     st_ptx(&red[tid], acc);
     __syncthreads();
+    PairPt a = ld_pair(&red[2 * pid], odd);
+    const PairPt b = ld_pair(&red[2 * pid + 1], odd);
+    __syncthreads();
+    pair_add(a, b, odd);
 #pragma unroll 1
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            const PtX o = ld_ptx(&red[tid + s]);
-            ptx_add<MulInline>(acc, o);
-            st_ptx(&red[tid], acc);
-        }
+    for (uint32_t half = 64; half > 0; half >>= 1) {
+        st_pair(&red[pid], a, odd);
         __syncthreads();
+        PairPt o = pair_identity();
+        if (pid < half) o = ld_pair(&red[pid + half], odd);
+        __syncthreads();
+        pair_add(a, o, odd);
     }
+    if (tid < 2) st_pair(dst, a, odd);
 }
 
 // ---- 5b. huge buckets (order[0..n_huge)): HUGE_PIECES workgroups each sum a slice of the bucket's
@@ -507,8 +515,7 @@ __global__ __launch_bounds__(256) void msm_huge_bucket_kernel(const g1x_affine_t
             const AffX p = load_point(points, e);
             ptx_madd(acc, p, entry_neg(e));
         }
-        block_sum_256(acc, red, tid);
-        if (tid == 0) st_ptx(pieces + (size_t)item * HUGE_PIECES + piece, acc);
+        block_sum_256(acc, red, tid, pieces + (size_t)item * HUGE_PIECES + piece);
         __syncthreads();
     }
 }
@@ -539,8 +546,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const g1x_affine_t*
                 ptx_madd(acc, p, entry_neg(e));
             }
         }
-        block_sum_256(acc, red, tid);
-        if (tid == 0) st_ptx(buckets + gid, acc);
+        block_sum_256(acc, red, tid, buckets + gid);
         __syncthreads();
     }
 }
