@@ -416,16 +416,25 @@ __global__ __launch_bounds__(256) void msm_bucket_split_kernel(const g1x_affine_
         const AffX p = load_point(points, e);
         ptx_madd(acc, p, entry_neg(e));
     }
+    // fold the LPB sums of a bucket, every addition run by a pair of its lanes (pair_add)
+    const uint32_t pid = tid >> 1, psub = pid & (LPB / 2 - 1);
+    const bool odd = (tid & 1u) != 0;
+    st_ptx(&red[tid], acc);
+    __syncthreads();
+    PairPt a = ld_pair(&red[2 * pid], odd);
+    const PairPt b = ld_pair(&red[2 * pid + 1], odd);
+    __syncthreads();
+    pair_add(a, b, odd);
 #pragma unroll 1
-    for (uint32_t half = LPB >> 1; half > 0; half >>= 1) {
-        st_ptx(&red[tid], acc);
+    for (uint32_t half = LPB >> 2; half > 0; half >>= 1) {
+        st_pair(&red[pid], a, odd);
         __syncthreads();
-        PtX o = ptx_identity();
-        if (sub < half) o = ld_ptx(&red[tid + half]);
+        PairPt o = pair_identity();
+        if (psub < half) o = ld_pair(&red[pid + half], odd);
         __syncthreads();
-        ptx_add<MulInline>(acc, o);
+        pair_add(a, o, odd);
     }
-    if (live && sub == 0) st_ptx(buckets + gid, acc);
+    if (live && psub == 0) st_pair(buckets + gid, a, odd);
 }
 
 // ---- 5a''. for the smallest inputs even that is a few long dependent chains per SIMD.  Here a PAIR of lanes runs each addition
