@@ -896,7 +896,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     } else {
         // lanes per bucket: a small bucket set with long buckets is spread over more lanes
         uint32_t log_lpb = 0;
-        while (log_lpb < 3 && (total_buckets << log_lpb) < (1u << 17) && (mean >> log_lpb) >= 16) ++log_lpb;
+        while (log_lpb < 3 && (total_buckets << log_lpb) < (1u << 18) && (mean >> log_lpb) >= 16) ++log_lpb;
         const uint32_t sblk = (uint32_t)((((size_t)total_buckets << log_lpb) + 255) / 256);
         if (log_lpb == 0)
             hipLaunchKernelGGL(msm_bucket_kernel, dim3(bblk), dim3(256), 0, st, points, s.sorted.p, s.offsets.p, s.counts.p,
