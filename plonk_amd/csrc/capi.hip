@@ -24,9 +24,12 @@ struct plonk_pk {
     Pk k;
 };
 
+// HIP's current device is per host thread: every entry point makes the context's device current
+// before it allocates or launches anything.
 #define API_BEGIN(ctxp) \
     Ctx* C_ = &(ctxp)->c; \
-    try {
+    try { \
+        HIP_CHECK(hipSetDevice(C_->device));
 #define API_END()                                   \
         return PLONK_OK;                            \
     } catch (const plonk::Error& e) {               \
@@ -276,6 +279,7 @@ int32_t plonk_pk_commitments(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs
     API_BEGIN(ctx)
     const Pk* k = reinterpret_cast<const Pk*>(pk);
     const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "pk commitments: key or SRS lives on another device");
     for (int q = 0; q < 8; ++q) g1_from_host(commit_checked(C_, s, k->coef.p + q * k->n, k->n), out + q);
     API_END()
 }
@@ -284,6 +288,7 @@ int32_t plonk_pk_poly(plonk_ctx* ctx, const plonk_pk* pk, uint32_t which, plonk_
     if (!ctx || !pk || !out_host || !len || which > 8) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     const Pk* k = reinterpret_cast<const Pk*>(pk);
+    PLONK_REQUIRE(k->device == C_->device, "pk poly: proving key lives on another device");
     HIP_CHECK(hipMemcpy(out_host, k->coef.p + which * k->n, k->n * sizeof(fr_t), hipMemcpyDeviceToHost));
     size_t l = k->n;
     while (l && (out_host[l - 1].l[0] | out_host[l - 1].l[1] | out_host[l - 1].l[2] | out_host[l - 1].l[3]) == 0) --l;
