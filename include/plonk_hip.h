@@ -89,6 +89,18 @@ int32_t plonk_ntt_dev(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32
 int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t flags,
                   const plonk_fr* shift, uint32_t batch, size_t stride);
 
+/* The same transform of ONE vector for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls
+ * no hipMalloc / hipFree: the intermediate image of the sweeps and the twiddle tables live in a
+ * static device array of 24.4 MiB that every GPU the library runs on holds until the process ends.
+ * log_n above plonk_ntt_noalloc_max_log_n() (= 18) returns PLONK_E_INVALID.  The array keeps the
+ * tables of the last (log_n, flags, shift); a call with another combination regenerates them with a
+ * few kernels on the ctx stream.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (two contexts, two threads) race. */
+int32_t plonk_ntt_dev_noalloc(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags,
+                              const plonk_fr* shift);
+uint32_t plonk_ntt_noalloc_max_log_n(void);
+
 /* ---- SRS + commit: replaces Srs (kzg.rs:26-35), Commitment::commit (kzg.rs:231-245) and
  * G1Projective::msm (curve.rs:169-173). ---- */
 /* Upload g1_powers[0..n) (kzg.rs:28).  Points must be on the curve; infinity allowed. */

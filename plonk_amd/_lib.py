@@ -68,6 +68,8 @@ SIGNATURES = {
     "plonk_dev_download": (_i32, [_vp, _vp, _vp, _sz]),
     "plonk_ntt_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _sz]),
     "plonk_ntt": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _sz]),
+    "plonk_ntt_dev_noalloc": (_i32, [_vp, _vp, _u32, _u32, _vp]),
+    "plonk_ntt_noalloc_max_log_n": (_u32, []),
     "plonk_srs_upload": (_i32, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "plonk_srs_from_tau": (_i32, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "plonk_srs_from_tau_range": (_i32, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),

@@ -59,6 +59,12 @@ int32_t plonk_ctx_create(int32_t device, plonk_ctx** out) {
         delete ctx;
         return PLONK_E_HIP;
     }
+    try {
+        ntt_noalloc_init(device);   // address of this device's static workspace (plonk_ntt_dev_noalloc)
+    } catch (const std::exception&) {
+        delete ctx;
+        return PLONK_E_HIP;
+    }
     *out = ctx;
     return PLONK_OK;
 }
@@ -141,6 +147,16 @@ int32_t plonk_ntt_dev(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32
     ntt_run_shift(C_, reinterpret_cast<fr_t*>(data_dev), log_n, flags, shift_or_default(shift), batch, stride);
     API_END()
 }
+
+int32_t plonk_ntt_dev_noalloc(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags, const plonk_fr* shift) {
+    if (!ctx) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    check_ntt_args(data_dev, log_n, flags, 1, 0);
+    ntt_run_noalloc(C_, reinterpret_cast<fr_t*>(data_dev), log_n, flags, shift_or_default(shift));
+    API_END()
+}
+
+uint32_t plonk_ntt_noalloc_max_log_n(void) { return ntt_noalloc_max_log_n(); }
 
 int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t flags, const plonk_fr* shift,
                   uint32_t batch, size_t stride) {

@@ -90,5 +90,8 @@ void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t 
 void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
                 size_t batch_stride);
 NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags);
+void ntt_noalloc_init(int device);
+uint32_t ntt_noalloc_max_log_n();
+void ntt_run_noalloc(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift);
 
 }  // namespace plonk

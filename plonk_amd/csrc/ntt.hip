@@ -249,12 +249,45 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Twiddle tables are generated on the device: entry [i][k] of a table is
+// c0 * bi^i * bk^k * bik^(i k), stored as a true value of the 29-bit-limb form (48-byte slot).
+// Field arithmetic is exact, so the entries are the same whichever way the powers are taken.
+struct TableGen {
+    fr_t c0, bi, bk, bik, k32;   // Montgomery residues; k32 = 32 (the radix change 2^256 -> 2^261)
+    uint32_t log_np;             // k runs over [0, 2^log_np)
+    uint32_t count;              // entries
+};
+
+__device__ __forceinline__ fr_t fr_pow_u64_dev(fr_t b, uint64_t e) {
+    fr_t r = f_one<FrP>();
+    while (e) {
+        if (e & 1ull) r = fr_mul(r, b);
+        b = fr_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void ntt_table_kernel(frx_slot* __restrict__ out, TableGen g) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.count) return;
+    const uint64_t i = idx >> g.log_np, k = idx & ((1u << g.log_np) - 1u);
+    fr_t v = fr_mul(g.c0, fr_pow_u64_dev(g.bk, k));
+    if (i) v = fr_mul(fr_mul(v, fr_pow_u64_dev(g.bi, i)), fr_pow_u64_dev(g.bik, i * k));
+    const frx x = x_repack_in<FrX>(fr_mul(v, g.k32));
+    uint4* q = reinterpret_cast<uint4*>(out + idx);
+    q[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    q[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    q[2] = make_uint4(x.l[8], 0u, 0u, 0u);
+}
+
 struct NttPlan {
     uint32_t log_n = 0, flags = 0, n_pass = 0;
     uint32_t R[NTT_MAX_PASSES] = {0, 0, 0, 0};
-    DevBuf<frx_slot> sub_tw;
-    DevBuf<frx_slot> pair[NTT_MAX_PASSES][NTT_MAX_PASSES];   // [p][q], p < q: step twiddles
-    DevBuf<frx_slot> pre, post;   // first sweep's input scale (forward coset), last sweep's output scale (inverse)
+    const frx_slot* sub_tw = nullptr;
+    const frx_slot* pair[NTT_MAX_PASSES][NTT_MAX_PASSES] = {};   // [p][q], p < q: step twiddles
+    const frx_slot *pre = nullptr, *post = nullptr;   // first sweep's input scale (forward coset), last sweep's output scale (inverse)
+    DevBuf<frx_slot> arena;   // owns the tables, unless they were placed in memory the caller provided
     host::fr_h shift;
 };
 
@@ -268,48 +301,60 @@ Ctx::~Ctx() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-// Montgomery (radix 2^256) host values -> x-form slots: times 2^5, regrouped into 29-bit limbs
-static void upload(DevBuf<frx_slot>& buf, const std::vector<host::fr_h>& v) {
-    const host::fr_h k32 = host::Fr::from_u64(32);
-    std::vector<frx_slot> x(v.size());
-    for (size_t i = 0; i < v.size(); ++i) {
-        const host::fr_h t = host::Fr::mul(v[i], k32);
-        memset(&x[i], 0, sizeof(frx_slot));
-        frx_words_from_u64(t.l, x[i].w);
-    }
-    buf.alloc(x.size());
-    if (!x.empty()) HIP_CHECK(hipMemcpy(buf.p, x.data(), x.size() * sizeof(frx_slot), hipMemcpyHostToDevice));
-}
-
-static std::vector<host::fr_h> powers(const host::fr_h& base, size_t count) {
-    std::vector<host::fr_h> v(count);
-    host::fr_h acc = host::Fr::one();
-    for (size_t i = 0; i < count; ++i) {
-        v[i] = acc;
-        acc = host::Fr::mul(acc, base);
-    }
-    return v;
-}
-
-static std::unique_ptr<NttPlan> build_plan(uint32_t log_n, uint32_t flags, const host::fr_h& shift) {
-    using host::Fr;
-    std::unique_ptr<NttPlan> pl(new NttPlan());
+static void plan_geometry(NttPlan* pl, uint32_t log_n, uint32_t flags) {
     pl->log_n = log_n;
     pl->flags = flags;
-    pl->shift = shift;
-    const bool inverse = flags & NTT_INVERSE, coset = flags & NTT_COSET;
-    // sweep sizes
-    uint32_t P = log_n <= NTT_TILE_LOG ? 1 : (log_n + 7) / 8;
+    const uint32_t P = log_n <= NTT_TILE_LOG ? 1 : (log_n + 7) / 8;
     PLONK_REQUIRE(P <= NTT_MAX_PASSES, "ntt: log_n out of range");
     pl->n_pass = P;
     for (uint32_t p = 0; p < P; ++p) pl->R[p] = log_n / P + (p < log_n % P ? 1 : 0);
+}
+
+// 48-byte slots the tables of a plan take
+static size_t plan_table_slots(const NttPlan* pl) {
+    const bool inverse = pl->flags & NTT_INVERSE, coset = pl->flags & NTT_COSET;
+    const uint32_t P = pl->n_pass;
+    size_t slots = (size_t)1 << (NTT_SUBTW_LOG - 1);
+    if (coset && !inverse) slots += (size_t)1 << pl->R[0];
+    if (inverse) slots += (size_t)1 << pl->R[P - 1];
+    for (uint32_t p = 0; p + 1 < P; ++p)
+        for (uint32_t q = p + 1; q < P; ++q) slots += (size_t)1 << (pl->R[p] + pl->R[q]);
+    return slots;
+}
+
+// Fills the tables of `pl` (geometry set) by kernels on `stream`; they live in `mem` (room for
+// plan_table_slots entries) or, when mem is null, in an arena the plan allocates.
+static void plan_build_tables(NttPlan* pl, const host::fr_h& shift, frx_slot* mem, hipStream_t stream) {
+    using host::Fr;
+    const uint32_t log_n = pl->log_n, P = pl->n_pass;
+    pl->shift = shift;
+    const bool inverse = pl->flags & NTT_INVERSE, coset = pl->flags & NTT_COSET;
+    if (!mem) {
+        pl->arena.alloc(plan_table_slots(pl));
+        mem = pl->arena.p;
+    }
+    frx_slot* cursor = mem;
+    const host::fr_h one = Fr::one();
+    const fr_t k32 = to_dev(Fr::from_u64(32));
+    auto gen = [&](const host::fr_h& c0, const host::fr_h& bi, const host::fr_h& bk, const host::fr_h& bik, uint32_t log_np,
+                   uint32_t log_ni) -> const frx_slot* {
+        TableGen g;
+        g.c0 = to_dev(c0); g.bi = to_dev(bi); g.bk = to_dev(bk); g.bik = to_dev(bik); g.k32 = k32;
+        g.log_np = log_np;
+        g.count = 1u << (log_np + log_ni);
+        frx_slot* dst = cursor;
+        cursor += g.count;
+        hipLaunchKernelGGL(ntt_table_kernel, dim3((g.count + 255) / 256), dim3(256), 0, stream, dst, g);
+        HIP_CHECK(hipGetLastError());
+        return dst;
+    };
     // twiddle tables of w = w_N (or its inverse)
     host::fr_h w = host::fr_root_of_unity(log_n);
     if (inverse) w = Fr::inv(w);
     {
         host::fr_h w11 = host::fr_root_of_unity(NTT_SUBTW_LOG);
         if (inverse) w11 = Fr::inv(w11);
-        upload(pl->sub_tw, powers(w11, (size_t)1 << (NTT_SUBTW_LOG - 1)));
+        pl->sub_tw = gen(one, one, w11, one, NTT_SUBTW_LOG - 1, 0);
     }
     // index algebra: input index = sum_q i_q S_q, output index = sum_p k_p M_p
     uint32_t log_S[NTT_MAX_PASSES], log_M[NTT_MAX_PASSES];
@@ -323,43 +368,29 @@ static std::unique_ptr<NttPlan> build_plan(uint32_t log_n, uint32_t flags, const
         }
     }
     const host::fr_h n_inv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
-    const host::fr_h g_inv = coset ? Fr::inv(shift) : Fr::one();
+    const host::fr_h g_inv = coset ? Fr::inv(shift) : one;
     // forward coset: coefficient i is scaled by g^i (fft.rs:129-133), i = sum_q i_q S_q.  The factor of
     // the first digit multiplies the input of the first sweep; that of digit q > 0 rides on the step
     // twiddles applied after sweep q-1.
-    if (coset && !inverse) upload(pl->pre, powers(Fr::pow_u64(shift, (uint64_t)1 << log_S[0]), (size_t)1 << pl->R[0]));
+    pl->pre = nullptr;
+    if (coset && !inverse) pl->pre = gen(one, one, Fr::pow_u64(shift, (uint64_t)1 << log_S[0]), one, pl->R[0], 0);
     // inverse: output K is scaled by 1/n (fft.rs:52-56) and, for the coset form, g^-K (fft.rs:147-152),
     // K = sum_p k_p M_p.  The factor of the last digit (and 1/n) multiplies the output of the last
     // sweep; that of digit p < P-1 rides on the step twiddles applied after sweep p.
-    if (inverse) {
-        std::vector<host::fr_h> v = powers(Fr::pow_u64(g_inv, (uint64_t)1 << log_M[P - 1]), (size_t)1 << pl->R[P - 1]);
-        for (auto& x : v) x = Fr::mul(x, n_inv);
-        upload(pl->post, v);
-    }
+    pl->post = nullptr;
+    if (inverse) pl->post = gen(n_inv, one, Fr::pow_u64(g_inv, (uint64_t)1 << log_M[P - 1]), one, pl->R[P - 1], 0);
+    for (uint32_t p = 0; p < NTT_MAX_PASSES; ++p)
+        for (uint32_t q = 0; q < NTT_MAX_PASSES; ++q) pl->pair[p][q] = nullptr;
     for (uint32_t p = 0; p + 1 < P; ++p) {
         for (uint32_t q = p + 1; q < P; ++q) {
-            const size_t np = (size_t)1 << pl->R[p], nq = (size_t)1 << pl->R[q];
-            std::vector<host::fr_h> t(np * nq);
-            // w^(M_p S_q) has order N / (M_p S_q) >= N_p N_q ... only products k i < N_p N_q occur
+            // entry [i][k] = step^(i k) gi^i gk^k; w^(M_p S_q) has order N / (M_p S_q) >= N_p N_q
             const host::fr_h step = Fr::pow_u64(w, (uint64_t)1 << (log_M[p] + log_S[q]));
             const bool neighbours = q == p + 1;
-            const host::fr_h gi = (coset && !inverse && neighbours) ? Fr::pow_u64(shift, (uint64_t)1 << log_S[q]) : Fr::one();
-            const host::fr_h gk = (coset && inverse && neighbours) ? Fr::pow_u64(g_inv, (uint64_t)1 << log_M[p]) : Fr::one();
-            const std::vector<host::fr_h> gk_pow = powers(gk, np);
-            host::fr_h base = Fr::one(), gi_pow = Fr::one();   // step^i, gi^i
-            for (size_t i = 0; i < nq; ++i) {
-                host::fr_h acc = gi_pow;                        // step^(i k) * gi^i, k = 0
-                for (size_t k = 0; k < np; ++k) {
-                    t[i * np + k] = Fr::mul(acc, gk_pow[k]);
-                    acc = Fr::mul(acc, base);
-                }
-                base = Fr::mul(base, step);
-                gi_pow = Fr::mul(gi_pow, gi);
-            }
-            upload(pl->pair[p][q], t);
+            const host::fr_h gi = (coset && !inverse && neighbours) ? Fr::pow_u64(shift, (uint64_t)1 << log_S[q]) : one;
+            const host::fr_h gk = (coset && inverse && neighbours) ? Fr::pow_u64(g_inv, (uint64_t)1 << log_M[p]) : one;
+            pl->pair[p][q] = gen(one, gi, gk, step, pl->R[p], pl->R[q]);
         }
     }
-    return pl;
 }
 
 static uint64_t plan_key(uint32_t log_n, uint32_t flags) { return (uint64_t)log_n | ((uint64_t)(flags & 3u) << 8); }
@@ -370,7 +401,10 @@ static NttPlan* get_plan_shift(Ctx* ctx, uint32_t log_n, uint32_t flags, const h
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end() && (!(flags & NTT_COSET) || it->second->shift == shift)) return it->second.get();
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // a replaced plan may still be in use
-    std::shared_ptr<NttPlan> pl(build_plan(log_n, flags, shift).release());
+    std::shared_ptr<NttPlan> pl(new NttPlan());
+    plan_geometry(pl.get(), log_n, flags);
+    plan_build_tables(pl.get(), shift, nullptr, ctx->stream);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // other streams of the context may run the plan next
     ctx->plans[key] = pl;
     return pl.get();
 }
@@ -379,19 +413,16 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
     return get_plan_shift(ctx, log_n, flags, host::Fr::from_u64(7));
 }
 
-static void ntt_launch(Ctx* ctx, hipStream_t stream, NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride) {
+// `tmp`: the intermediate image of a multi-sweep transform (as large as the strided batch); unused
+// when the plan has one sweep.
+static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride,
+                       fr_t* tmp) {
     const uint32_t log_n = pl->log_n, P = pl->n_pass;
     if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
     if (!ctx->ntt_lds_attr_set) {   // per device, and a context belongs to one device
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         ctx->ntt_lds_attr_set = true;
-    }
-    fr_t* tmp = nullptr;
-    if (P > 1) {
-        const size_t need = (size_t)(batch - 1) * batch_stride + ((size_t)1 << log_n);
-        ctx->ntt_tmp.ensure(need);
-        tmp = ctx->ntt_tmp.p;
     }
     uint32_t log_h = 0;
     uint32_t log_s = log_n;
@@ -403,15 +434,15 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, NttPlan* pl, fr_t* data, ui
         memset(&a, 0, sizeof(a));
         a.in = (p == 0) ? data : tmp;
         a.out = last ? data : tmp;
-        a.pre = p == 0 ? pl->pre.p : nullptr;
-        a.post = last ? pl->post.p : nullptr;
-        a.sub_tw = pl->sub_tw.p;
+        a.pre = p == 0 ? pl->pre : nullptr;
+        a.post = last ? pl->post : nullptr;
+        a.sub_tw = pl->sub_tw;
         a.n_pairs = P - 1 - p;
         {
             uint32_t ls = log_s;   // log2 S_p; S_q for q > p follows by peeling R[q]
             for (uint32_t q = p + 1; q < P; ++q) {
                 ls -= pl->R[q];
-                a.pair_tab[q - p - 1] = pl->pair[p][q].p;
+                a.pair_tab[q - p - 1] = pl->pair[p][q];
                 a.pair_shift[q - p - 1] = ls;
                 a.pair_mask[q - p - 1] = (1u << pl->R[q]) - 1u;
             }
@@ -437,6 +468,13 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, NttPlan* pl, fr_t* data, ui
     }
 }
 
+// the context's own intermediate image, grown on demand
+static fr_t* ctx_tmp(Ctx* ctx, const NttPlan* pl, uint32_t batch, size_t batch_stride) {
+    if (pl->n_pass <= 1) return nullptr;
+    ctx->ntt_tmp.ensure((size_t)(batch - 1) * batch_stride + ((size_t)1 << pl->log_n));
+    return ctx->ntt_tmp.p;
+}
+
 void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride) {
     ntt_run_on(ctx, ctx->stream, data_dev, log_n, flags, batch, batch_stride);
 }
@@ -446,13 +484,66 @@ void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t 
 void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
                 size_t batch_stride) {
     NttPlan* pl = ntt_get_plan(ctx, log_n, flags);
-    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride);
+    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride));
 }
 
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
                    size_t batch_stride) {
     NttPlan* pl = get_plan_shift(ctx, log_n, flags, shift);
-    ntt_launch(ctx, ctx->stream, pl, data_dev, batch, batch_stride);
+    ntt_launch(ctx, ctx->stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride));
+}
+
+// ------------------------------------------------------------------------------------------
+// A transform that allocates nothing, for callers that cannot call hipMalloc (HIP graph capture,
+// serving loops, harnesses that forbid it).  Its intermediate image and its twiddle tables live in a
+// static device array; every GPU the library runs on holds its own copy at its own address.
+static constexpr uint32_t NOALLOC_MAX_LOG_N = 18;
+static constexpr size_t NOALLOC_IMAGE_BYTES = ((size_t)1 << NOALLOC_MAX_LOG_N) * 48;   // intermediate image
+static constexpr size_t NOALLOC_TABLE_BYTES = (((size_t)1 << NOALLOC_MAX_LOG_N) + 8192) * sizeof(frx_slot);
+static constexpr size_t NOALLOC_SCRATCH_BYTES = NOALLOC_IMAGE_BYTES + NOALLOC_TABLE_BYTES;   // 24.4 MiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+static constexpr int NOALLOC_MAX_DEVICES = 64;
+struct NoAllocState {
+    unsigned char* ptr = nullptr;   // this device's address of `scratch`
+    bool plan_valid = false;
+    NttPlan plan;                   // tables inside the scratch array (arena stays empty)
+};
+static NoAllocState g_noalloc[NOALLOC_MAX_DEVICES];
+
+// Set-up, once per device with that device current (plonk_ctx_create calls it): the array's name is
+// a host-side stand-in; only the address looked up here may be handed to kernels.
+void ntt_noalloc_init(int device) {
+    PLONK_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "ntt: device index out of range");
+    NoAllocState& st = g_noalloc[device];
+    if (st.ptr) return;
+    void* p = nullptr;
+    HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    st.ptr = static_cast<unsigned char*>(p);
+}
+
+uint32_t ntt_noalloc_max_log_n() { return NOALLOC_MAX_LOG_N; }
+
+// One vector of 2^log_n elements, in place, on ctx->stream.  The static workspace keeps the tables
+// of the last (log_n, flags, shift) it was used with; another combination regenerates them by a
+// few kernels on the same stream.  Nothing in the workspace has to start at zero: the tables and the
+// intermediate image are written in full before they are read.
+void ntt_run_noalloc(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift) {
+    PLONK_REQUIRE(log_n <= NOALLOC_MAX_LOG_N, "ntt (no-alloc): size above the 2^18 elements the static workspace holds");
+    NoAllocState& st = g_noalloc[ctx->device];
+    PLONK_REQUIRE(st.ptr != nullptr, "ntt (no-alloc): static workspace of this device was not set up");
+    const bool same = st.plan_valid && st.plan.log_n == log_n && st.plan.flags == flags &&
+                      (!(flags & NTT_COSET) || st.plan.shift == shift);
+    if (!same) {
+        st.plan_valid = false;
+        plan_geometry(&st.plan, log_n, flags);
+        PLONK_REQUIRE(plan_table_slots(&st.plan) * sizeof(frx_slot) <= NOALLOC_TABLE_BYTES &&
+                          ((size_t)sizeof(fr_t) << log_n) <= NOALLOC_IMAGE_BYTES,
+                      "ntt (no-alloc): transform does not fit the static workspace");
+        plan_build_tables(&st.plan, shift, reinterpret_cast<frx_slot*>(st.ptr + NOALLOC_IMAGE_BYTES), ctx->stream);
+        st.plan_valid = true;
+    }
+    ntt_launch(ctx, ctx->stream, &st.plan, data_dev, 1, 0, reinterpret_cast<fr_t*>(st.ptr));
 }
 
 }  // namespace plonk
