@@ -1,9 +1,11 @@
 """bench.py -- prover wall time at 2^k gates on N MI355X, with NTT / MSM rates and rooflines.
 
 One step = one proof (plonk_prove_3wire_dev) of the synthetic 2^k-gate circuit, witness resident
-in HBM.  N > 1: one process per GPU (torch.distributed / RCCL); every rank holds the full key, the
-nine commitment MSMs are sharded by point range and their partial sums exchanged.
-Prints ONE JSON line on rank 0.
+in HBM.  N > 1: one process per GPU; every rank holds the full key, the nine commitment MSMs are
+sharded by point range and the ranks' shares all-gathered on the device by the library's RCCL
+communicator (torch.distributed/gloo only carries the RCCL id, the barriers and the max over ranks).
+`python bench.py --gpus N` starts the N ranks itself; under torch.distributed.run (WORLD_SIZE set)
+the process is one of the ranks.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -87,6 +89,29 @@ def cpu_baseline(log_n):
             "ntt_gbps": round(64.0 * (1 << ls) / t_ntt / 1e9, 3), "msm_mpoints_per_s": round(m / t_msm / 1e6, 4)}
 
 
+def launch_ranks(n_ranks):
+    """Start one fresh child process per rank (this process has not touched a GPU and does not), wait
+    for all of them, print rank 0's JSON line.  Any failing rank fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        sys.stderr.write("bench.py: rank exit codes %r; rank 0 printed %d JSON line(s)\n" % (codes, len(lines)))
+        sys.exit(1)
+    print(lines[-1], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,24 +121,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the NTT / MSM rates at the other sizes")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)   # before anything in this process touches a GPU
 
-    import numpy as np
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N`, or under "
+                 "torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    import numpy as np
+    import torch
     dist = None
-    # rehearsal on a box with fewer GPUs than ranks: PLONK_BENCH_BACKEND=gloo, ranks share the devices
+    # PLONK_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks: the ranks
+    # share the devices and the library stages its all-gathers through the host (RCCL wants a GPU per rank)
     backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")   # control plane only: RCCL id, barriers, max over ranks
     import plonk_amd as pa
     from plonk_amd import circuits, sharded
 
@@ -122,7 +152,7 @@ def main():
     n = 1 << k
     t0 = time.time()
     circ = circuits.SyntheticCircuit(k)
-    comm = sharded.Communicator(dist, rank, world, local_rank) if world > 1 else None
+    comm = sharded.Communicator(ctx, dist, rank, world, kind="rccl" if backend == "nccl" else "callback") if world > 1 else None
     lo, hi = sharded.point_range(n + 11, rank, world)
     srs = pa.Srs.from_tau(circ.tau, n + 10, ctx=ctx) if world == 1 else pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
     pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
@@ -145,7 +175,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
@@ -199,7 +229,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic 2^%d-gate mul/add chain, 3-wire PLONK prove, witness "
                                    "resident in HBM, SRS/proving key preloaded" % k,
-                       "parallelism": "1 GPU" if world == 1 else "msm point-range sharding over %d GPUs, partial sums all-gathered" % world,
+                       "parallelism": "1 GPU" if world == 1 else "msm point-range sharding over %d GPUs, shares all-gathered on "
+                                      "the device (%s)" % (world, comm.kind),
                        "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest},
             "ntt_gbps": round(ntt_rate / 1e9, 2), "ntt_ms_coset_2^%d" % log4: round(ntt_ms, 4),
             "msm_mpoints_per_s": round(n / msm_s / 1e6, 3), "msm_ms_2^%d" % k: round(msm_s * 1e3, 3),

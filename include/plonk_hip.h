@@ -167,18 +167,35 @@ int32_t plonk_prove_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, const plonk_sr
                               const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev, const plonk_fr* public_inputs,
                               size_t n_public_inputs, const plonk_fr blinding[11], plonk_proof* out);
 
-/* ---- multi-GPU: the nine commitment MSMs sharded by point range, one process per GPU.
- * `srs_slice` holds g1_powers[shard_lo, shard_lo + len) (plonk_srs_from_tau_range or an upload of
- * that slice); every rank passes the same witness and key.  After each local partial MSM the
- * library calls `allgather(user, send, bytes, recv)`, which must fill recv with the `bytes`-sized
- * records of all `world` ranks in rank order (RCCL/NCCL all-gather in practice) and return 0.
- * All ranks obtain the same proof.  No counterpart in the single-process reference. */
+/* ---- multi-GPU: one process per GPU, the nine commitment MSMs sharded by point range.  No
+ * counterpart in the single-process reference.
+ * A plonk_comm is this rank's end of an all-gather among the `world` ranks of a proof.  The RCCL
+ * form exchanges device buffers over xGMI (ncclAllGather on the ctx stream): rank 0 obtains an id
+ * with plonk_comm_unique_id, the launcher hands its bytes to every rank, and all ranks call
+ * plonk_comm_create_rccl (a collective call; one GPU per rank).  The callback form stages each record
+ * through host memory and calls `allgather(user, send, bytes, recv)`, which must fill recv with the
+ * `bytes`-sized records of all ranks in rank order and return 0; it exists to rehearse the
+ * multi-rank path where RCCL cannot run (several ranks sharing one GPU, CPU-side collectives). */
+#define PLONK_COMM_ID_BYTES 128
+typedef struct plonk_comm plonk_comm;
 typedef int32_t (*plonk_allgather_fn)(void* user, const void* send, size_t bytes, void* recv);
+int32_t plonk_comm_unique_id(uint8_t out[PLONK_COMM_ID_BYTES]);
+int32_t plonk_comm_create_rccl(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+                               plonk_comm** out);
+int32_t plonk_comm_create_callback(plonk_ctx* ctx, uint32_t rank, uint32_t world, plonk_allgather_fn allgather,
+                                   void* user, plonk_comm** out);
+void plonk_comm_destroy(plonk_comm* comm);
+/* All-gathers issued through this handle and the bytes this rank contributed to them. */
+int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* bytes);
+/* Prover::prove with the commitments sharded: `srs_slice` holds g1_powers[shard_lo, shard_lo + len)
+ * (plonk_srs_from_tau_range or an upload of that slice) and the ranks' slices must tile the point
+ * range in rank order (checked; PLONK_E_INVALID otherwise).  Every rank passes the same witness and
+ * key and makes the same call; the ranks' shares of every MSM (the window sums of its reduction)
+ * are all-gathered on the device and combined by every rank, so all ranks obtain the same proof. */
 int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
-                                  uint32_t world, plonk_allgather_fn allgather, void* user,
-                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
-                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
-                                  plonk_proof* out);
+                                  plonk_comm* comm, const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev,
+                                  const plonk_fr* c_evals_dev, const plonk_fr* public_inputs, size_t n_public_inputs,
+                                  const plonk_fr blinding[11], plonk_proof* out);
 /* Sum of n affine points on the host (combining per-rank partial commitments). */
 int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out);
 /* Window width c (bits) the MSM uses for n points: W = ceil(256/c) windows of 2^(c-1) buckets. */

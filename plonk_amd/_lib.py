@@ -18,6 +18,7 @@ PLONK_E_INTERNAL = -4
 NTT_INVERSE = 1
 NTT_COSET = 2
 PROOF_WIRE_BYTES = 624
+COMM_ID_BYTES = 128
 
 
 class PlonkError(RuntimeError):
@@ -86,7 +87,12 @@ SIGNATURES = {
     "plonk_quotient_3wire_dev": (_i32, [_vp] * 11),
     "plonk_prove_3wire": (_i32, [_vp] * 7 + [_sz, _vp, _vp]),
     "plonk_prove_3wire_dev": (_i32, [_vp] * 7 + [_sz, _vp, _vp]),
-    "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "plonk_comm_unique_id": (_i32, [_vp]),
+    "plonk_comm_create_rccl": (_i32, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "plonk_comm_create_callback": (_i32, [_vp, _u32, _u32, _vp, _vp, C.POINTER(_vp)]),
+    "plonk_comm_destroy": (None, [_vp]),
+    "plonk_comm_stats": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "plonk_g1_sum": (_i32, [_vp, _sz, _vp]),
     "plonk_msm_window_bits": (_u32, [_sz]),
     "plonk_msm_set_timing": (_i32, [_vp, _i32]),

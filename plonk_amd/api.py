@@ -507,6 +507,9 @@ class Prover:
     def __init__(self, wires, pk, srs, resident=False, comm=None, shard=None):
         """comm/shard: multi-GPU proving (plonk_amd.sharded): `srs` is then this rank's slice
         [shard[0], shard[1]) of g1_powers and `comm` a sharded.Communicator."""
+        if comm is not None:
+            if shard is None or len(shard) != 2 or shard[1] - shard[0] != len(srs):
+                raise PlonkError(_lib.PLONK_E_INVALID, "sharded proving needs shard=(lo, hi) with hi - lo = len(srs)")
         self.pk, self.srs = pk, srs
         self.wires = [_as_limbs(w, pk.n) for w in wires]
         self.dev = None
@@ -534,8 +537,8 @@ class Prover:
         raw = _lib.Proof()
         ctx = self.pk.ctx
         if self.comm is not None:
-            ctx.check(lib.plonk_prove_3wire_sharded(ctx.h, self.pk.h, self.srs.h, self.shard[0], self.comm.world,
-                                                    self.comm.callback, None, self.dev[0], self.dev[1], self.dev[2],
+            ctx.check(lib.plonk_prove_3wire_sharded(ctx.h, self.pk.h, self.srs.h, self.shard[0], self.comm.h,
+                                                    self.dev[0], self.dev[1], self.dev[2],
                                                     pis, len(public_inputs), bl, C.byref(raw)))
         elif self.dev:
             ctx.check(lib.plonk_prove_3wire_dev(ctx.h, self.pk.h, self.srs.h, self.dev[0], self.dev[1], self.dev[2],

@@ -23,6 +23,15 @@ struct plonk_srs {
 struct plonk_pk {
     Pk k;
 };
+struct plonk_comm {
+    std::unique_ptr<Exchange> ex;
+};
+
+// A failed call may leave kernels of an abandoned MSM batch on the context's streams.
+static void drain_after_error(Ctx* c) {
+    msm_drain(c);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+}
 
 // HIP's current device is per host thread: every entry point makes the context's device current
 // before it allocates or launches anything.
@@ -34,12 +43,15 @@ struct plonk_pk {
         return PLONK_OK;                            \
     } catch (const plonk::Error& e) {               \
         C_->last_error = e.what();                  \
+        drain_after_error(C_);                      \
         return e.code;                              \
     } catch (const std::bad_alloc&) {               \
         C_->last_error = "out of host memory";      \
+        drain_after_error(C_);                      \
         return PLONK_E_NOMEM;                       \
     } catch (const std::exception& e) {             \
         C_->last_error = e.what();                  \
+        drain_after_error(C_);                      \
         return PLONK_E_INTERNAL;                    \
     }
 
@@ -351,24 +363,64 @@ int32_t plonk_prove_3wire_dev(plonk_ctx* ctx, const plonk_pk* pk, const plonk_sr
     API_END()
 }
 
+int32_t plonk_comm_unique_id(uint8_t out[PLONK_COMM_ID_BYTES]) {
+    if (!out) return PLONK_E_INVALID;
+    try {
+        comm_unique_id(out);
+    } catch (const plonk::Error& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return PLONK_E_INTERNAL;
+    }
+    return PLONK_OK;
+}
+
+int32_t plonk_comm_create_rccl(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+                               plonk_comm** out) {
+    if (!ctx || !id || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    std::unique_ptr<plonk_comm> c(new plonk_comm());
+    c->ex.reset(comm_create_rccl(C_->device, id, rank, world));
+    *out = c.release();
+    API_END()
+}
+
+int32_t plonk_comm_create_callback(plonk_ctx* ctx, uint32_t rank, uint32_t world, plonk_allgather_fn allgather, void* user,
+                                   plonk_comm** out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    std::unique_ptr<plonk_comm> c(new plonk_comm());
+    c->ex.reset(comm_create_callback(C_->device, rank, world, allgather, user));
+    *out = c.release();
+    API_END()
+}
+
+void plonk_comm_destroy(plonk_comm* comm) { delete comm; }
+
+int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* bytes) {
+    if (!comm || !calls || !bytes) return PLONK_E_INVALID;
+    *calls = comm->ex->calls;
+    *bytes = comm->ex->bytes;
+    return PLONK_OK;
+}
+
 int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
-                                  uint32_t world, plonk_allgather_fn allgather, void* user,
-                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
-                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
-                                  plonk_proof* out) {
-    if (!ctx || !pk || !srs_slice || !a_evals_dev || !b_evals_dev || !c_evals_dev || !blinding || !out) return PLONK_E_INVALID;
+                                  plonk_comm* comm, const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev,
+                                  const plonk_fr* c_evals_dev, const plonk_fr* public_inputs, size_t n_public_inputs,
+                                  const plonk_fr blinding[11], plonk_proof* out) {
+    if (!ctx || !pk || !srs_slice || !comm || !a_evals_dev || !b_evals_dev || !c_evals_dev || !blinding || !out)
+        return PLONK_E_INVALID;
     if (n_public_inputs && !public_inputs) return PLONK_E_INVALID;
     API_BEGIN(ctx)
-    PLONK_REQUIRE(world >= 1, "prove: world must be >= 1");
-    PLONK_REQUIRE(world == 1 || allgather != nullptr, "prove: sharded proving needs an all-gather callback");
     const Pk* k = reinterpret_cast<const Pk*>(pk);
     const Srs* s = reinterpret_cast<const Srs*>(srs_slice);
     PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
+    PLONK_REQUIRE(comm->ex->world > 1 || shard_lo == 0, "prove: a single rank holds the whole point range");
     ShardInfo sh;
     sh.lo = shard_lo;
-    sh.world = world;
-    sh.allgather = allgather;
-    sh.user = user;
+    sh.ex = comm->ex.get();
     prove_3wire(C_, k, s, a_evals_dev, b_evals_dev, c_evals_dev, true, public_inputs, n_public_inputs, blinding, out, &sh);
     API_END()
 }

@@ -1,0 +1,125 @@
+// The two all-gather implementations behind comm.hpp.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, which resolves to the copy already loaded in the
+// process if there is one): a single-GPU user of the library never loads it, and the library has no
+// link-time dependency on it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <vector>
+
+#include "comm.hpp"
+
+namespace plonk {
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    static std::string failure;
+    std::call_once(once, [] {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* e = dlerror();
+            failure = std::string("cannot load RCCL: ") + (e ? e : "unknown error");
+            return;
+        }
+        api.handle = h;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
+            failure = "RCCL library lacks an expected entry point";
+            api.handle = nullptr;
+        }
+    });
+    if (!api.handle) throw Error(PLONK_E_HIP, failure);
+    return api;
+}
+
+void rccl_check(ncclResult_t rc, const char* what) {
+    if (rc != ncclSuccess) throw Error(PLONK_E_HIP, std::string(what) + ": " + rccl().GetErrorString(rc));
+}
+
+struct RcclExchange : Exchange {
+    ncclComm_t comm = nullptr;
+    ~RcclExchange() override {
+        if (comm) {
+            (void)hipSetDevice(device);
+            (void)rccl().CommDestroy(comm);
+        }
+    }
+    void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
+        rccl_check(rccl().AllGather(send_dev, recv_dev, nbytes, ncclUint8, comm, stream), "ncclAllGather");
+        ++calls;
+        bytes += nbytes;
+    }
+    const char* kind() const override { return "rccl"; }
+};
+
+struct CallbackExchange : Exchange {
+    plonk_allgather_fn fn = nullptr;
+    void* user = nullptr;
+    std::vector<uint8_t> send, recv;
+    void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
+        send.resize(nbytes);
+        recv.resize(nbytes * world);
+        HIP_CHECK(hipMemcpyAsync(send.data(), send_dev, nbytes, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (fn(user, send.data(), nbytes, recv.data()) != 0) throw Error(PLONK_E_INTERNAL, "all-gather callback failed");
+        HIP_CHECK(hipMemcpyAsync(recv_dev, recv.data(), nbytes * world, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));   // `recv` is reused by the next call
+        ++calls;
+        bytes += nbytes;
+    }
+    const char* kind() const override { return "callback"; }
+};
+
+}  // namespace
+
+void comm_unique_id(uint8_t out[COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out, &id, COMM_ID_BYTES);
+}
+
+Exchange* comm_create_rccl(int device, const uint8_t id_bytes[COMM_ID_BYTES], uint32_t rank, uint32_t world) {
+    PLONK_REQUIRE(world >= 1 && rank < world, "comm: rank must be below world");
+    std::unique_ptr<RcclExchange> ex(new RcclExchange());
+    ex->rank = rank;
+    ex->world = world;
+    ex->device = device;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, COMM_ID_BYTES);
+    rccl_check(rccl().CommInitRank(&ex->comm, (int)world, id, (int)rank), "ncclCommInitRank");
+    return ex.release();
+}
+
+Exchange* comm_create_callback(int device, uint32_t rank, uint32_t world, plonk_allgather_fn fn, void* user) {
+    PLONK_REQUIRE(world >= 1 && rank < world, "comm: rank must be below world");
+    PLONK_REQUIRE(fn != nullptr, "comm: null all-gather callback");
+    std::unique_ptr<CallbackExchange> ex(new CallbackExchange());
+    ex->rank = rank;
+    ex->world = world;
+    ex->device = device;
+    ex->fn = fn;
+    ex->user = user;
+    return ex.release();
+}
+
+}  // namespace plonk

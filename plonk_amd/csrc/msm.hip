@@ -731,10 +731,18 @@ struct MsmSlot {
     DevBuf<g1_xyzz_t> sums;
     g1_xyzz_t* host_sums = nullptr;   // pinned, so the device-to-host copy stays asynchronous
     size_t host_cap = 0;
+    // sharded MSM: this rank's record (header + sums), the records of all ranks, and their pinned landing buffer
+    DevBuf<unsigned char> record, gathered;
+    unsigned char* host_gathered = nullptr;
+    uint32_t* host_hdr = nullptr;     // pinned staging of the record header
+    size_t host_gathered_cap = 0;
+    uint32_t world = 0;               // ranks whose records host_gathered holds; 0 = a local MSM
     uint32_t c = 0, W = 0, nq = 0, log_chunks = 0, chunk_log = 0;
     bool empty = true;
     ~MsmSlot() {
         if (host_sums) (void)hipHostFree(host_sums);
+        if (host_gathered) (void)hipHostFree(host_gathered);
+        if (host_hdr) (void)hipHostFree(host_hdr);
         if (host_entries) (void)hipHostFree(host_entries);
         for (auto& e : t_ev)
             if (e) (void)hipEventDestroy(e);
@@ -777,19 +785,53 @@ static MsmWorkspace* msm_workspace(Ctx* ctx) {
     return static_cast<MsmWorkspace*>(ctx->msm_ws.get());
 }
 
+// One rank's share of a sharded MSM as it is all-gathered: a 64-byte header (empty flag, window width,
+// bucket sets, sums per set, log2 chunks, log2 buckets per chunk) and the sums of the reduction,
+// at most 256 of them (W <= 64 windows of at most 4 sums at c = 4, one set of at most 20 with the
+// window table).  The ranks' shares may differ in size and hence in geometry, so each record
+// describes itself.
+static constexpr size_t MSM_REC_HDR = 64;
+static constexpr size_t MSM_REC_SUMS = 256;
+static constexpr size_t MSM_REC_BYTES = MSM_REC_HDR + MSM_REC_SUMS * sizeof(g1_xyzz_t);
+
+static void msm_exchange(Ctx* ctx, MsmSlot& s, Exchange* ex, bool empty) {
+    hipStream_t st = ctx->stream;
+    if (!s.host_hdr) HIP_CHECK(hipHostMalloc((void**)&s.host_hdr, MSM_REC_HDR, hipHostMallocDefault));
+    s.record.ensure(MSM_REC_BYTES);
+    s.gathered.ensure(MSM_REC_BYTES * ex->world);
+    if (MSM_REC_BYTES * ex->world > s.host_gathered_cap) {
+        if (s.host_gathered) (void)hipHostFree(s.host_gathered);
+        s.host_gathered = nullptr;
+        HIP_CHECK(hipHostMalloc((void**)&s.host_gathered, MSM_REC_BYTES * ex->world, hipHostMallocDefault));
+        s.host_gathered_cap = MSM_REC_BYTES * ex->world;
+    }
+    memset(s.host_hdr, 0, MSM_REC_HDR);
+    s.host_hdr[0] = empty ? 1u : 0u;
+    s.host_hdr[1] = s.c; s.host_hdr[2] = s.W; s.host_hdr[3] = s.nq; s.host_hdr[4] = s.log_chunks; s.host_hdr[5] = s.chunk_log;
+    HIP_CHECK(hipMemcpyAsync(s.record.p, s.host_hdr, MSM_REC_HDR, hipMemcpyHostToDevice, st));
+    ex->allgather(s.record.p, s.gathered.p, MSM_REC_BYTES, st);
+    HIP_CHECK(hipMemcpyAsync(s.host_gathered, s.gathered.p, MSM_REC_BYTES * ex->world, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(s.done_ev, st));
+}
+
 // Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the sort
 // stream behind it).
 static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts, const fr_t* scalars, size_t n,
-                        bool tail_phase) {
+                        bool tail_phase, Exchange* ex) {
     const g1x_affine_t* points = pts.px;
     // the shared bucket set is used unless the input is a sliver of the SRS (n < 2^(table_c - 12))
     const uint32_t shared = (pts.table_c && (n >> (pts.table_c > 12 ? pts.table_c - 12 : 0)) != 0) ? 1u : 0u;
     MsmSlot& s = ws->slot[si];
     s.empty = n == 0;
-    if (n == 0) return;
+    s.world = ex ? ex->world : 0;
+    if (n == 0) {
+        if (ex && tail_phase) msm_exchange(ctx, s, ex, true);   // an empty share still takes part in the all-gather
+        return;
+    }
     PLONK_REQUIRE(n < ((size_t)1 << 31), "msm: too many points");
     const uint32_t c = shared ? pts.table_c : msm_window_bits(n);
     const uint32_t W = (256 + c - 1) / c;
+    PLONK_REQUIRE((uint64_t)W * n < ((uint64_t)1 << 32), "msm: too many (point, window) entries for 32-bit offsets");
     const uint32_t S = shared ? 1u : W;   // bucket sets
     const uint32_t nbk = 1u << (c - 1);
     const uint32_t total_buckets = S * nbk;
@@ -839,6 +881,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     s.arow.ensure((size_t)S * rows);
     s.col.ensure((size_t)S * cols);
     s.sums.ensure((size_t)S * nq);
+    PLONK_REQUIRE(!ex || (size_t)S * nq <= MSM_REC_SUMS, "msm: too many window sums for the exchange record");
     if ((size_t)S * nq > s.host_cap) {
         if (s.host_sums) (void)hipHostFree(s.host_sums);
         s.host_sums = nullptr;
@@ -935,40 +978,73 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     }
     hipLaunchKernelGGL(msm_rowcol_kernel, dim3(2 * rows + cols, S), dim3(ROWCOL_LANES), 0, st, chunk_a, chunk_r, log_chunks, ml, s.row.p,
                        s.arow.p, s.col.p);
-    hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(MASKED_LANES), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, s.sums.p);
+    g1_xyzz_t* sums_out = s.sums.p;
+    if (ex) {
+        s.record.ensure(MSM_REC_BYTES);
+        sums_out = reinterpret_cast<g1_xyzz_t*>(s.record.p + MSM_REC_HDR);
+    }
+    hipLaunchKernelGGL(msm_masked_kernel, dim3(nq, S), dim3(MASKED_LANES), 0, st, s.row.p, s.arow.p, s.col.p, log_chunks, ml, sums_out);
     HIP_CHECK(hipGetLastError());
+    if (ex) {
+        msm_exchange(ctx, s, ex, false);
+        if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[4], st));
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(s.host_sums, s.sums.p, (size_t)S * nq * sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, st));
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[4], st));
     HIP_CHECK(hipEventRecord(s.done_ev, st));
 }
 
-// Wait for slot `si` and combine on the host: S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w.
+// S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w, from the sums of one reduction
+static host::G1XyzzH combine_sums(const g1_xyzz_t* sums, uint32_t c, uint32_t W, uint32_t nq, uint32_t log_chunks,
+                                  uint32_t chunk_log) {
+    host::G1XyzzH acc = host::g1_identity();
+    for (int w = (int)W - 1; w >= 0; --w) {
+        if (w != (int)W - 1)
+            for (uint32_t k = 0; k < c; ++k) acc = host::g1_double(acc);
+        const g1_xyzz_t* q = sums + (size_t)w * nq;
+        host::G1XyzzH g = host::g1_identity();
+        for (int i = (int)log_chunks - 1; i >= 0; --i) {
+            g = host::g1_double(g);
+            g = host::g1_add(g, xyzz_to_host(q[1 + i]));
+        }
+        for (uint32_t k = 0; k < chunk_log; ++k) g = host::g1_double(g);
+        g = host::g1_add(g, xyzz_to_host(q[0]));
+        acc = host::g1_add(acc, g);
+    }
+    return acc;
+}
+
+// Wait for slot `si` and combine on the host; a sharded MSM adds up the shares of all ranks, in rank order.
 static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
     MsmSlot& s = ws->slot[si];
     host::G1AffineH ident;
     ident.x = host::Fq::zero(); ident.y = host::Fq::zero(); ident.inf = true;
-    if (s.empty) return ident;
+    if (s.world == 0) {
+        if (s.empty) return ident;
+        HIP_CHECK(hipEventSynchronize(s.done_ev));
+        return host::g1_to_affine(combine_sums(s.host_sums, s.c, s.W, s.nq, s.log_chunks, s.chunk_log));
+    }
     HIP_CHECK(hipEventSynchronize(s.done_ev));
     host::G1XyzzH acc = host::g1_identity();
-    for (int w = (int)s.W - 1; w >= 0; --w) {
-        if (w != (int)s.W - 1)
-            for (uint32_t k = 0; k < s.c; ++k) acc = host::g1_double(acc);
-        const g1_xyzz_t* q = s.host_sums + (size_t)w * s.nq;
-        host::G1XyzzH g = host::g1_identity();
-        for (int i = (int)s.log_chunks - 1; i >= 0; --i) {
-            g = host::g1_double(g);
-            g = host::g1_add(g, xyzz_to_host(q[1 + i]));
-        }
-        for (uint32_t k = 0; k < s.chunk_log; ++k) g = host::g1_double(g);
-        g = host::g1_add(g, xyzz_to_host(q[0]));
-        acc = host::g1_add(acc, g);
+    for (uint32_t r = 0; r < s.world; ++r) {
+        const unsigned char* rec = s.host_gathered + (size_t)r * MSM_REC_BYTES;
+        uint32_t hdr[6];
+        memcpy(hdr, rec, sizeof(hdr));
+        if (hdr[0]) continue;
+        if (hdr[1] < 1 || hdr[1] > 31 || hdr[2] < 1 || hdr[3] < 1 || (size_t)hdr[2] * hdr[3] > MSM_REC_SUMS ||
+            hdr[4] + 1 != hdr[3] || hdr[5] > 31)
+            throw Error(PLONK_E_INTERNAL, "msm: malformed share in the all-gathered records");
+        acc = host::g1_add(acc, combine_sums(reinterpret_cast<const g1_xyzz_t*>(rec + MSM_REC_HDR), hdr[1], hdr[2], hdr[3],
+                                             hdr[4], hdr[5]));
     }
     return host::g1_to_affine(acc);
 }
 
-host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler) {
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler,
+                        Exchange* ex) {
     host::G1AffineH out;
-    msm_run_batch(ctx, pts, &scalars_dev, &n, 1, &out, filler);
+    msm_run_batch(ctx, pts, &scalars_dev, &n, 1, &out, filler, ex);
     return out;
 }
 
@@ -983,13 +1059,13 @@ void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n) {
     HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
     b.scalars[b.count] = scalars_dev;
     b.n[b.count] = n;
-    msm_enqueue(ctx, ws, b.count, b.pts, scalars_dev, n, false);
+    msm_enqueue(ctx, ws, b.count, b.pts, scalars_dev, n, false, b.ex);
     ++b.count;
 }
 
 void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFiller& filler) {
     MsmWorkspace* ws = msm_workspace(ctx);
-    for (int k = 0; k < b.count; ++k) msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], true);
+    for (int k = 0; k < b.count; ++k) msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], true, b.ex);
     if (filler) {
         // behind what ctx->stream held when the last MSM was added (not behind the reductions above)
         if (b.count == 0) HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
@@ -1003,17 +1079,27 @@ void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFill
 }
 
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
-                   host::G1AffineH* out, const MsmFiller& filler) {
+                   host::G1AffineH* out, const MsmFiller& filler, Exchange* ex) {
     static_assert(MSM_BATCH_MAX == MsmWorkspace::SLOTS, "one workspace slot per MSM of a batch");
     for (int k = 0; k < count; ++k) PLONK_REQUIRE(n[k] <= pts.level_stride, "msm: more scalars than points");
     MsmBatch b;
     b.pts = pts;
+    b.ex = ex;
     for (int base = 0; base < count; base += MSM_BATCH_MAX) {
         const int m = std::min(MSM_BATCH_MAX, count - base);
         for (int k = 0; k < m; ++k) msm_batch_add(ctx, b, scalars_dev[base + k], n[base + k]);
         msm_batch_finish(ctx, b, out + base, base + m == count ? filler : MsmFiller());
     }
     if (count == 0 && filler) msm_batch_finish(ctx, b, out, filler);
+}
+
+// After a failed call: wait for whatever the MSM streams still hold, so that the next call does not
+// rewrite a slot's buffers under a kernel of the abandoned batch.
+void msm_drain(Ctx* ctx) {
+    if (!ctx->msm_ws) return;
+    MsmWorkspace* ws = static_cast<MsmWorkspace*>(ctx->msm_ws.get());
+    if (ws->sort_stream) (void)hipStreamSynchronize(ws->sort_stream);
+    if (ws->bucket_stream) (void)hipStreamSynchronize(ws->bucket_stream);
 }
 
 // Timing marks are recorded only while enabled (extra events on the MSM streams).

@@ -2,6 +2,7 @@
 #pragma once
 #include <functional>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "g1.cuh"
 #include "g1x.cuh"
@@ -36,14 +37,19 @@ uint32_t msm_table_bits(size_t n);
 // them is enqueued, so what it launches there runs beside the final (latency-bound) reduction instead
 // of after it.  msm_run / msm_run_batch return with ctx->stream ordered behind that work.
 typedef std::function<void(hipStream_t)> MsmFiller;
-host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler = nullptr);
+// With an Exchange the MSM is one rank's share of a sharded one: the per-window sums of all ranks are
+// all-gathered on the device and every rank combines them, so every rank returns the whole sum.  All
+// ranks must then make the same sequence of MSM calls (an empty share included).
+host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev, size_t n, const MsmFiller& filler = nullptr,
+                        Exchange* ex = nullptr);
 void msm_run_batch(Ctx* ctx, const MsmPoints& pts, const fr_t* const* scalars_dev, const size_t* n, int count,
-                   host::G1AffineH* out, const MsmFiller& filler = nullptr);
+                   host::G1AffineH* out, const MsmFiller& filler = nullptr, Exchange* ex = nullptr);
 // The same in two steps, for a caller that prepares the scalar vectors one after the other.
 constexpr int MSM_BATCH_MAX = 3;
 struct MsmBatch {
     MsmPoints pts;
     int count = 0;
+    Exchange* ex = nullptr;
     const fr_t* scalars[MSM_BATCH_MAX];
     size_t n[MSM_BATCH_MAX];
 };
@@ -54,6 +60,7 @@ struct MsmTiming {
     uint64_t entries;
     uint32_t window_bits, bucket_sets;
 };
+void msm_drain(Ctx* ctx);
 void msm_set_timing(Ctx* ctx, bool on);
 void msm_last_timing(Ctx* ctx, MsmTiming* out);
 void g1_convert_to_xform(Ctx* ctx, const g1_affine_t* in, size_t n, g1x_affine_t* out);

@@ -227,6 +227,7 @@ struct ProverWorkspace {
     DevBuf<fr_t> evals;   // [8]
     DevBuf<fr_t> totals, partial;
     DevBuf<uint32_t> flag;
+    DevBuf<uint64_t> xchg;   // sharded proving: (lo, count) of every rank's SRS slice
 };
 
 static ProverWorkspace* prover_workspace(Ctx* ctx) {
@@ -247,56 +248,51 @@ host::G1AffineH g1_sum_affine(const plonk_g1* pts, size_t n) {
     return host::g1_to_affine(acc);
 }
 
+// a communicator of one rank still runs its (trivial) all-gathers: the same code path for every world size
+static bool sharded(const ShardInfo* shard) { return shard && shard->ex; }
+
+// This rank's part [lo, hi) of a polynomial of `len` coefficients: all of it (clipped to the SRS) on
+// one GPU, the slice of the rank's SRS points otherwise.  Coefficients past the last SRS point must be
+// zero: kzg.rs:232-238 strips trailing zeros before its length check and panics otherwise; here the
+// flag is raised, identically on every rank (they all hold the whole polynomial).
+static void commit_range(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev, const ShardInfo* shard,
+                         size_t* lo, size_t* hi) {
+    const size_t end = sharded(shard) ? shard->global_end : srs->n;
+    if (len > end) poly_nonzero_check(ctx, coeffs, (uint32_t)end, (uint32_t)len, flag_dev);
+    if (sharded(shard)) {
+        *lo = std::min(shard->lo, len);
+        *hi = std::min(shard->lo + srs->n, len);
+    } else {
+        *lo = 0;
+        *hi = std::min(len, srs->n);
+    }
+}
+
 static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
                                   const ShardInfo* shard = nullptr, const MsmFiller& filler = nullptr) {
-    // kzg.rs:231-245.  Coefficients past the SRS must be zero (the reference strips trailing zeros
-    // before its length check and panics otherwise).
-    if (!shard || shard->world <= 1) {
-        size_t m = std::min(len, srs->n);
-        if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
-        return msm_run(ctx, msm_points(srs), coeffs, m, filler);
-    }
-    // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
-    const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
-    host::G1AffineH part = msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo, filler);
-    plonk_g1 mine;
-    g1_from_host(part, &mine);
-    std::vector<plonk_g1> all(shard->world);
-    const int rc = shard->allgather(shard->user, &mine, sizeof(plonk_g1), all.data());
-    if (rc != 0) throw Error(PLONK_E_INTERNAL, "commit: all-gather of the MSM partial sums failed");
-    return g1_sum_affine(all.data(), all.size());
+    size_t lo, hi;
+    commit_range(ctx, srs, coeffs, len, flag_dev, shard, &lo, &hi);
+    return msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo, filler, sharded(shard) ? shard->ex : nullptr);
 }
 
 // Several commitments against the same SRS, overlapped on the device (independent MSMs on
 // separate streams).  commit_add starts one as soon as its coefficients are ready on ctx->stream;
-// commit_finish collects them.  Sharded runs exchange one partial sum per commitment.
+// commit_finish collects them.  Sharded runs all-gather the ranks' shares inside the MSM.
 static void commit_add(Ctx* ctx, const Srs* srs, MsmBatch& b, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
                        const ShardInfo* shard) {
-    if (b.count == 0) b.pts = msm_points(srs);
-    if (!(shard && shard->world > 1)) {
-        if (len > srs->n) poly_nonzero_check(ctx, coeffs, (uint32_t)srs->n, (uint32_t)len, flag_dev);
-        msm_batch_add(ctx, b, coeffs, std::min(len, srs->n));
-    } else {   // this rank's slice [lo, lo + srs->n) of the point range, clipped to the polynomial
-        const size_t lo = std::min(shard->lo, len), hi = std::min(shard->lo + srs->n, len);
-        msm_batch_add(ctx, b, coeffs + lo, hi - lo);
+    if (b.count == 0) {
+        b.pts = msm_points(srs);
+        b.ex = sharded(shard) ? shard->ex : nullptr;
     }
+    size_t lo, hi;
+    commit_range(ctx, srs, coeffs, len, flag_dev, shard, &lo, &hi);
+    msm_batch_add(ctx, b, coeffs + lo, hi - lo);
 }
 
 static void commit_finish(Ctx* ctx, MsmBatch& b, const ShardInfo* shard, host::G1AffineH* out,
                           const MsmFiller& filler = nullptr) {
-    const int count = b.count;
+    (void)shard;
     msm_batch_finish(ctx, b, out, filler);
-    if (shard && shard->world > 1) {
-        std::vector<plonk_g1> mine(count), all((size_t)count * shard->world);
-        for (int k = 0; k < count; ++k) g1_from_host(out[k], &mine[k]);
-        const int rc = shard->allgather(shard->user, mine.data(), sizeof(plonk_g1) * count, all.data());
-        if (rc != 0) throw Error(PLONK_E_INTERNAL, "commit: all-gather of the MSM partial sums failed");
-        std::vector<plonk_g1> col(shard->world);
-        for (int k = 0; k < count; ++k) {
-            for (uint32_t r = 0; r < shard->world; ++r) col[r] = all[(size_t)r * count + k];
-            out[k] = g1_sum_affine(col.data(), col.size());
-        }
-    }
 }
 
 static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
@@ -304,6 +300,27 @@ static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, co
     MsmBatch b;
     for (int k = 0; k < count; ++k) commit_add(ctx, srs, b, coeffs[k], lens[k], flag_dev, shard);
     commit_finish(ctx, b, shard, out, filler);
+}
+
+// The ranks' SRS slices must tile [0, global_end) in rank order; every rank learns global_end.
+static void shard_check_coverage(Ctx* ctx, ProverWorkspace* ws, const Srs* srs, ShardInfo* shard) {
+    Exchange* ex = shard->ex;
+    ws->xchg.ensure(2 + 2 * (size_t)ex->world);
+    const uint64_t mine[2] = {shard->lo, srs->n};
+    HIP_CHECK(hipMemcpyAsync(ws->xchg.p, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ex->allgather(ws->xchg.p, ws->xchg.p + 2, sizeof(mine), ctx->stream);
+    std::vector<uint64_t> all(2 * (size_t)ex->world);
+    HIP_CHECK(hipMemcpyAsync(all.data(), ws->xchg.p + 2, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PLONK_REQUIRE(all[2 * ex->rank] == shard->lo && all[2 * ex->rank + 1] == srs->n,
+                  "prove: the all-gather does not return this rank's record at its rank index");
+    uint64_t next = 0;
+    for (uint32_t r = 0; r < ex->world; ++r) {
+        PLONK_REQUIRE(all[2 * r] == next, "prove: the ranks' SRS slices do not tile the point range (gap or overlap)");
+        next += all[2 * r + 1];
+    }
+    shard->global_end = next;
 }
 
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
@@ -327,7 +344,7 @@ static void check_flag(Ctx* ctx, ProverWorkspace* ws) {
 
 void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
                  bool evals_on_device, const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out,
-                 const ShardInfo* shard) {
+                 const ShardInfo* shard_in) {
     const size_t n = pk->n, n4 = 4 * n, ns = n + 8;
     const uint32_t log_n = pk->log_n;
     ProverWorkspace* ws = prover_workspace(ctx);
@@ -335,6 +352,14 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     ws->num.ensure(n); ws->den.ensure(n); ws->scr.ensure(n); ws->tp.ensure(3 * ns);
     ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->wq2.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
     hipStream_t st = ctx->stream;
+    ShardInfo shard_local;
+    const ShardInfo* shard = nullptr;
+    if (sharded(shard_in)) {
+        PLONK_REQUIRE(shard_in->ex->device == ctx->device, "prove: the communicator belongs to another device");
+        shard_local = *shard_in;
+        shard_check_coverage(ctx, ws, srs, &shard_local);
+        shard = &shard_local;
+    }
     fr_h bl[11];
     for (int i = 0; i < 11; ++i) {
         memcpy(bl[i].l, blinding[i].l, 32);

@@ -25,12 +25,11 @@ struct Pk {
 };
 
 // Point-range sharding of the commitment MSMs over the ranks of one node: this rank's SRS handle
-// holds g1_powers[lo, lo + srs->n); `allgather` exchanges one plonk_g1 per rank (rank order).
+// holds g1_powers[lo, lo + srs->n); `ex` all-gathers the ranks' shares of every MSM on the device.
 struct ShardInfo {
     size_t lo = 0;
-    uint32_t world = 1;
-    plonk_allgather_fn allgather = nullptr;
-    void* user = nullptr;
+    Exchange* ex = nullptr;
+    size_t global_end = 0;   // one past the last SRS point any rank holds (set by the prover)
 };
 
 Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const host::fr_h& k1,

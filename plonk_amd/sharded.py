@@ -1,9 +1,11 @@
 """Multi-GPU proving: one process per GPU, the nine commitment MSMs sharded by point range.
 
-Every rank holds the proving key and the witness (the NTT / quotient phases are replicated);
-rank r holds the SRS slice point_range(n_points, r, world) and computes the partial MSM over
-it; the 104-byte partial sums are all-gathered (RCCL over xGMI with the "nccl" backend, gloo on
-CPU) and added in rank order on every rank, so all ranks derive the same transcript and proof.
+Every rank holds the proving key and the witness; rank r holds the SRS slice
+point_range(n_points, r, world) and computes its share of every MSM over it.  The shares (the
+window sums of each rank's bucket reduction) are all-gathered on the device inside the library --
+ncclAllGather over xGMI with the RCCL communicator, or staged through the host and a
+torch.distributed (gloo) all-gather with the callback communicator -- and combined in rank order by
+every rank, so all ranks derive the same transcript and proof.
 """
 import ctypes as C
 
@@ -18,26 +20,22 @@ def point_range(n_points, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-class Communicator:
-    """All-gather of fixed-size byte records over torch.distributed, callable from the C library."""
+class HostAllGather:
+    """All-gather of fixed-size byte records over torch.distributed with host tensors (gloo),
+    callable from the C library as a plonk_allgather_fn."""
 
-    def __init__(self, dist, rank, world, local_rank=None):
-        import torch
+    def __init__(self, dist, rank, world):
         self.dist, self.rank, self.world = dist, rank, world
-        backend = dist.get_backend()
-        self.device = torch.device("cuda", local_rank if local_rank is not None else rank) if backend == "nccl" \
-            else torch.device("cpu")
         self.calls = 0
         self.callback = _lib.ALLGATHER_FN(self._allgather)  # keep a reference: the C side holds the pointer
 
     def allgather_bytes(self, payload):
         import torch
-        send = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
-        recv = torch.empty(self.world * len(payload), dtype=torch.uint8, device=self.device)
-        self.dist.all_gather_into_tensor(recv, send) if self.device.type == "cuda" else \
-            self.dist.all_gather(list(recv.chunk(self.world)), send)
+        send = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        recv = torch.empty(self.world * len(payload), dtype=torch.uint8)
+        self.dist.all_gather(list(recv.chunk(self.world)), send)
         self.calls += 1
-        return bytes(recv.cpu().numpy().tobytes())
+        return recv.numpy().tobytes()
 
     def _allgather(self, user, send, nbytes, recv):
         try:
@@ -48,6 +46,54 @@ class Communicator:
             import sys
             print("plonk_amd.sharded: all-gather failed: %r" % (e,), file=sys.stderr)
             return -1
+
+
+class Communicator:
+    """This rank's plonk_comm.  kind "rccl": device buffers over xGMI; the 128-byte RCCL id is made by
+    rank 0 and handed to the other ranks through `dist` (any torch.distributed group, gloo will do --
+    it carries nothing else).  kind "callback": the records are staged through the host and
+    exchanged by `dist` itself (rehearsal where RCCL cannot run: ranks sharing one GPU)."""
+
+    def __init__(self, ctx, dist, rank, world, kind="rccl"):
+        self.ctx, self.rank, self.world, self.kind = ctx, rank, world, kind
+        self.host = None
+        h = C.c_void_p()
+        if kind == "rccl":
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+            if rank == 0:
+                rc = _lib.lib.plonk_comm_unique_id(ident)
+                if rc != 0:
+                    raise _lib.PlonkError(rc, "plonk_comm_unique_id failed (is RCCL installed?)")
+            box = [bytes(ident)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+            ctx.check(_lib.lib.plonk_comm_create_rccl(ctx.h, ident, rank, world, C.byref(h)))
+        elif kind == "callback":
+            self.host = HostAllGather(dist, rank, world)
+            ctx.check(_lib.lib.plonk_comm_create_callback(ctx.h, rank, world, self.host.callback, None, C.byref(h)))
+        else:
+            raise ValueError("communicator kind must be 'rccl' or 'callback'")
+        self.h = h
+
+    def stats(self):
+        """(all-gathers issued, bytes this rank contributed)."""
+        calls, nbytes = C.c_uint64(), C.c_uint64()
+        rc = _lib.lib.plonk_comm_stats(self.h, C.byref(calls), C.byref(nbytes))
+        if rc != 0:
+            raise _lib.PlonkError(rc, "plonk_comm_stats")
+        return calls.value, nbytes.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib.plonk_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def combine_partials(points):

@@ -1,7 +1,8 @@
-"""world_size-2 rehearsal of the sharded-commit exchange on CPU (gloo): point-range split,
-all-gather of the per-rank partial commitments through the same callback object the C library
-calls, and the host-side combine (plonk_g1_sum).  The per-rank partial MSMs come from the oracle
-here (no GPU); on MI355X they come from the HIP MSM through plonk_prove_3wire_sharded."""
+"""world_size-2 rehearsal of the sharded-commit exchange.  On CPU (gloo): point-range split,
+all-gather of per-rank records through the same callback object the C library calls, and the
+host-side combine (plonk_g1_sum); the per-rank partial MSMs come from the oracle there (no GPU).
+On MI355X: plonk_prove_3wire_sharded itself, two ranks on one GPU with the callback communicator,
+one rank with the RCCL communicator, and bench.py started with --gpus 2."""
 import os
 import subprocess
 import sys
@@ -18,7 +19,7 @@ from oracle import curve, protocol as P
 import random
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-comm = sharded.Communicator(dist, rank, world)
+comm = sharded.HostAllGather(dist, rank, world)
 n_points = 37
 srs = P.Srs(0xD15EA5E, n_points - 1)
 rng = random.Random(5)
@@ -88,15 +89,33 @@ k = 16
 circ = circuits.SyntheticCircuit(k)
 n = circ.n
 ctx = pa.Context(0)   # both ranks share the one GPU of the test box
-comm = sharded.Communicator(dist, rank, world)
+comm = sharded.Communicator(ctx, dist, rank, world, kind="callback")
 lo, hi = sharded.point_range(n + 11, rank, world)
 srs = pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
 assert len(srs) == hi - lo
 pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
 proof = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi)).prove([], circ.blinding)
-assert comm.calls == 4, comm.calls   # one exchange per round of commitments: 3 + 1 + 3 + 2 MSMs
+calls, nbytes = comm.stats()
+assert calls == 1 + 9, calls   # the coverage check, then one all-gather per commitment MSM
+assert comm.host.calls == calls
 want = [e for e in json.load(open(os.path.join(%(root)r, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
 assert proof.to_bytes().hex() == want["proof"], "sharded proof differs from the single-device golden proof"
+# slices that do not tile the point range are refused on every rank (the single-device prover
+# returns PLONK_E_INVALID for a polynomial past the SRS; a gap would silently drop coefficients)
+bad = pa.Srs.from_tau_range(circ.tau, lo + (1 if rank else 0), hi, ctx=ctx)
+try:
+    pa.Prover(circ.wires, pk, bad, resident=True, comm=comm, shard=(lo + (1 if rank else 0), hi)).prove([], circ.blinding)
+    raise SystemExit("a gap in the point range was accepted")
+except pa.PlonkError as e:
+    assert e.code == pa._lib.PLONK_E_INVALID and "tile" in str(e), e
+# ... and so is an SRS whose ranks together hold fewer points than the blinded polynomials need
+lo2, hi2 = sharded.point_range(n + 1, rank, world)
+short = pa.Srs.from_tau_range(circ.tau, lo2, hi2, ctx=ctx)
+try:
+    pa.Prover(circ.wires, pk, short, resident=True, comm=comm, shard=(lo2, hi2)).prove([], circ.blinding)
+    raise SystemExit("a too-short sharded SRS was accepted")
+except pa.PlonkError as e:
+    assert e.code == pa._lib.PLONK_E_INVALID, e
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -129,3 +148,53 @@ def test_sharded_prove_two_ranks_one_gpu(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert "rank %d ok" % rank in out
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_single_rank(ctx):
+    """The RCCL communicator with one rank (all this box can host: RCCL wants a GPU per rank):
+    librccl is bound at run time, ncclCommInitRank / ncclAllGather run on the context's stream, and the
+    sharded prover -- same code path as with more ranks -- returns the golden 2^16 proof."""
+    import json
+    import plonk_amd as pa
+    from plonk_amd import circuits, sharded
+    k = 16
+    circ = circuits.SyntheticCircuit(k)
+    n = circ.n
+    comm = sharded.Communicator(ctx, None, 0, 1, kind="rccl")
+    srs = pa.Srs.from_tau_range(circ.tau, 0, n + 11, ctx=ctx)
+    pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
+    proof = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(0, n + 11)).prove([], circ.blinding)
+    want = [e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
+    assert proof.to_bytes().hex() == want["proof"]
+    calls, nbytes = comm.stats()
+    assert calls == 10 and nbytes == 16 + 9 * (64 + 256 * 192)
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` starts two ranks by itself (both on this box's one GPU, exchange staged
+    through gloo) and reports n_gpus = 2 and the same proof as the one-rank run."""
+    import json
+
+    def run(gpus):
+        env = dict(os.environ, PLONK_BENCH_BACKEND="gloo")
+        env.pop("WORLD_SIZE", None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--log-n", "14", "--steps", "2",
+                              "--warmup", "1", "--no-sweep", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=280)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    one, two = run(1), run(2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["proof_sha256_16"] == one["config"]["proof_sha256_16"]
+    assert two["steps"] == 2 and two["value"] > 0
+    # asking for more ranks than WORLD_SIZE provides is an error, not a silent one-rank run
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0 and b"WORLD_SIZE" in bad.stderr
