@@ -82,7 +82,8 @@ int32_t plonk_dev_download(plonk_ctx* ctx, void* dst_host, const void* src_dev, 
  * In place over `batch` vectors of 2^log_n Fr, vector b at data + b*stride (elements).
  * flags: PLONK_NTT_INVERSE, PLONK_NTT_COSET.  `shift` is the coset generator k (Montgomery
  * Fr); NULL means 7, the value prover.rs:367 uses.  The inverse transform scales by 1/n and,
- * with COSET, by k^-i, exactly as fft.rs:52-56,147-152.  log_n in [0, 32]. */
+ * with COSET, by k^-i, exactly as fft.rs:52-56,147-152.  log_n in [0, 28] (the field's two-adicity
+ * would allow 32; 2^27, the 8n domain of a 2^24-gate circuit, is the largest size exercised). */
 int32_t plonk_ntt_dev(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags,
                       const plonk_fr* shift, uint32_t batch, size_t stride);
 /* Same over a host buffer (upload, transform, download). */
@@ -103,7 +104,8 @@ uint32_t plonk_ntt_noalloc_max_log_n(void);
 
 /* ---- SRS + commit: replaces Srs (kzg.rs:26-35), Commitment::commit (kzg.rs:231-245) and
  * G1Projective::msm (curve.rs:169-173). ---- */
-/* Upload g1_powers[0..n) (kzg.rs:28).  Points must be on the curve; infinity allowed. */
+/* Upload g1_powers[0..n) (kzg.rs:28), n < 2^31.  Every point is checked against the curve equation
+ * (on the device) and its coordinates against q: PLONK_E_INVALID otherwise; infinity allowed. */
 int32_t plonk_srs_upload(plonk_ctx* ctx, const plonk_g1* g1_powers, size_t n, plonk_srs** out);
 /* [tau^i]_1 for i in [0, n) generated on the device from a known tau (Montgomery Fr):
  * the group elements of Srs::from_tau (kzg.rs:71-94).  For synthetic benchmarks and tests. */
@@ -128,7 +130,7 @@ int32_t plonk_msm(plonk_ctx* ctx, const plonk_g1* points_host, const plonk_fr* s
 /* ---- proving key: replaces preprocess (plonk/preprocess.rs:104-186) and ProvingKey
  * (plonk/types.rs:12).  Inputs are the per-gate selector vectors (constraint.rs:385-393) and the
  * S_sigma evaluation vectors of Permutation::compute (permutation.rs:113-126), each n = 2^log_n
- * Montgomery Fr on the host.  k1, k2 are the coset generators (permutation.rs:61-62).
+ * Montgomery Fr on the host, log_n in [2, 26].  k1, k2 are the coset generators (permutation.rs:61-62).
  * pi_positions are ConstraintSystem::public_input_positions.  The key keeps, resident on the
  * device, the nine coefficient vectors (q_M..q_C, S_sigma1..3, L1) and their evaluations on
  * the 4n coset 7*H (what prover.rs:380-392 recomputes for every proof). */

@@ -137,7 +137,7 @@ int32_t plonk_dev_download(plonk_ctx* ctx, void* dst_host, const void* src_dev, 
 
 static void check_ntt_args(const void* data, uint32_t log_n, uint32_t flags, uint32_t batch, size_t stride) {
     PLONK_REQUIRE(data != nullptr, "ntt: null data");
-    PLONK_REQUIRE(log_n <= 32, "ntt: size must be a power of two no larger than 2^32 (field two-adicity)");
+    PLONK_REQUIRE(log_n <= 28, "ntt: size must be a power of two no larger than 2^28");
     PLONK_REQUIRE((flags & ~3u) == 0, "ntt: unknown flag");
     PLONK_REQUIRE(batch >= 1, "ntt: batch must be >= 1");
     PLONK_REQUIRE(batch == 1 || stride >= ((size_t)1 << log_n), "ntt: batch stride smaller than the transform");

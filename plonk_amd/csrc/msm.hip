@@ -1221,15 +1221,27 @@ static void srs_build_points(Ctx* ctx, Srs* s, bool with_table) {
     s->levels = W;
 }
 
+// *flag |= 1 if some point (other than the (0, 0) image of the identity) is off y^2 = x^3 + 4
+__global__ __launch_bounds__(256) void g1_on_curve_kernel(const g1_affine_t* __restrict__ pts, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const g1_affine_t p = ld_affine(pts + i);
+    if (affine_is_inf(p)) return;
+    fq_t four = f_one<FqP>();
+    four = fq_add(four, four);
+    four = fq_add(four, four);
+    const fq_t rhs = fq_add(fq_mul(fq_mul(p.x, p.x), p.x), four);
+    if (!f_eq<FqP>(fq_mul(p.y, p.y), rhs)) atomicOr(flag, 1u);
+}
+
 Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n, bool with_table) {
+    PLONK_REQUIRE(n < ((size_t)1 << 31), "srs: too many points");
     for (size_t i = 0; i < n; ++i) {
         if (pts[i].infinity) continue;
-        host::G1AffineH a;
-        memcpy(a.x.l, pts[i].x, 48);
-        memcpy(a.y.l, pts[i].y, 48);
-        a.inf = false;
-        PLONK_REQUIRE(!host::Fq::geq_p(a.x) && !host::Fq::geq_p(a.y), "srs: coordinate not reduced");
-        if (i < 4 || i + 1 == n) PLONK_REQUIRE(host::g1_on_curve(a), "srs: point not on the curve");
+        host::fq_h x, y;
+        memcpy(x.l, pts[i].x, 48);
+        memcpy(y.l, pts[i].y, 48);
+        PLONK_REQUIRE(!host::Fq::geq_p(x) && !host::Fq::geq_p(y), "srs: coordinate not reduced");
     }
     std::unique_ptr<Srs> s(new Srs());
     s->device = ctx->device;
@@ -1237,7 +1249,19 @@ Srs* srs_upload(Ctx* ctx, const plonk_g1* pts, size_t n, bool with_table) {
     std::vector<g1_affine_t> packed;
     g1_pack(pts, n, packed);
     s->points.alloc(n);
-    if (n) HIP_CHECK(hipMemcpy(s->points.p, packed.data(), n * sizeof(g1_affine_t), hipMemcpyHostToDevice));
+    if (n) {
+        HIP_CHECK(hipMemcpy(s->points.p, packed.data(), n * sizeof(g1_affine_t), hipMemcpyHostToDevice));
+        // every point must satisfy the curve equation (checked where the points now are)
+        DevBuf<uint32_t> flag(1);
+        HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(g1_on_curve_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, s->points.p, (uint32_t)n,
+                           flag.p);
+        HIP_CHECK(hipGetLastError());
+        uint32_t bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PLONK_REQUIRE(bad == 0, "srs: point not on the curve");
+    }
     srs_build_points(ctx, s.get(), with_table);
     return s.release();
 }

@@ -104,7 +104,7 @@ static void upload_fr(DevBuf<fr_t>& buf, const std::vector<fr_h>& v) {
 
 Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const fr_h& k1,
               const fr_h& k2, const uint32_t* pi_pos, size_t n_pi_pos) {
-    PLONK_REQUIRE(log_n >= 2 && log_n <= 28, "pk: domain size must be 2^2 .. 2^28");
+    PLONK_REQUIRE(log_n >= 2 && log_n <= 26, "pk: domain size must be 2^2 .. 2^26");
     std::unique_ptr<Pk> pk(new Pk());
     const size_t n = (size_t)1 << log_n, n4 = 4 * n;
     pk->device = ctx->device;
@@ -381,7 +381,9 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     for (size_t i = 0; i < n_pub; ++i) tr.absorb_fr("pi_" + std::to_string(i), pi[i]);  // :69-71
 
     HIP_CHECK(hipMemsetAsync(ws->flag.p, 0, 16, st));
-    HIP_CHECK(hipMemsetAsync(ws->w4.p, 0, 5 * n4 * sizeof(fr_t), st));
+    // a, b, c, z: [0, n) is overwritten by the evaluations, the blinding lands on [n, n + 3), and the coset
+    // transform reads all 4n: only the tails have to start at zero
+    for (int k = 0; k < 4; ++k) HIP_CHECK(hipMemsetAsync(W[k] + n, 0, (n4 - n) * sizeof(fr_t), st));
     HIP_CHECK(hipMemsetAsync(ws->co.p, 0, 4 * ns * sizeof(fr_t), st));
     HIP_CHECK(hipMemsetAsync(ws->tp.p, 0, 3 * ns * sizeof(fr_t), st));
 
@@ -448,6 +450,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     if (n_pub && !pk->pi_positions.empty()) {  // prover.rs:840-857
         std::vector<fr_h> pe(n, Fr::zero());
         for (size_t i = 0; i < pk->pi_positions.size() && i < n_pub; ++i) pe[pk->pi_positions[i]] = Fr::neg(pi[i]);
+        HIP_CHECK(hipMemsetAsync(W[4] + n, 0, (n4 - n) * sizeof(fr_t), st));
         HIP_CHECK(hipMemcpyAsync(W[4], pe.data(), n * sizeof(fr_t), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));
         ntt_run(ctx, W[4], log_n, NTT_INVERSE, 1, 0);

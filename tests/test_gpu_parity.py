@@ -131,6 +131,63 @@ def test_ntt_full_size_properties(ctx, log_n):
         assert pa.fr_from_array(fd[k:k + 1]) == [7 * pow(w, k, R_MOD) % R_MOD]
 
 
+def test_ntt_largest_size(ctx):
+    """2^27 points = the 8n domain of a 2^24-gate circuit, four sweeps, 4 GiB per vector (the header
+    admits up to 2^28): known transforms of a sparse vector at a few positions, then the inverse
+    brings the dense image back to the sparse input bit for bit."""
+    import plonk_amd as pa
+    log_n = 27
+    n = 1 << log_n
+    idx = [0, 1, 5, n // 2 + 3, n - 1]
+    vals = _rand(27, len(idx))
+    dev = ctx.alloc(n * 32)
+    try:
+        sparse = np.zeros((n, 4), dtype=np.uint64)
+        sparse[idx] = pa.fr_to_array(vals)
+        ctx.upload(dev, sparse)
+        ctx.ntt_dev(dev, log_n, 2)
+        w = root_of_unity(n)
+        for k in (0, 1, 2, 12345, n // 2, n - 7, n - 1):
+            got = ctx.download(C.c_void_p(dev.value + 32 * k), 32).reshape(1, 4)
+            x = 7 * pow(w, k, R_MOD) % R_MOD
+            assert pa.fr_from_array(got) == [sum(v * pow(x, i, R_MOD) for i, v in zip(idx, vals)) % R_MOD], k
+        ctx.ntt_dev(dev, log_n, 3)
+        back = ctx.download(dev, n * 32).reshape(n, 4)
+        assert np.array_equal(back, sparse)
+    finally:
+        ctx.free(dev)
+    with pytest.raises(pa.PlonkError):
+        ctx.ntt_dev(dev, 29, 0)   # beyond the stated limit
+
+
+def test_context_used_from_another_thread(ctx):
+    """A context may be handed from thread to thread (one at a time).  HIP's current device is per
+    thread, so every entry point makes the context's device current itself."""
+    import threading
+    import plonk_amd as pa
+    v = _rand(3, 1 << 12)
+    want = offt.coset_fft(v, root_of_unity(1 << 12), 7, 1 << 12)
+    box = {}
+
+    def work():
+        try:
+            c2 = pa.Context(0)
+            box["own"] = pa.fr_from_array(c2.ntt(pa.fr_to_array(v), 2))
+            box["shared"] = pa.fr_from_array(ctx.ntt(pa.fr_to_array(v), 2))
+            srs = pa.Srs.from_tau(99, 63, ctx=c2)
+            box["commit"] = pa.Commitment.commit(v[:64], srs).point
+            c2.close()
+        except Exception as e:   # surfaced in the main thread
+            box["error"] = e
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "error" not in box, box.get("error")
+    assert box["own"] == want and box["shared"] == want
+    assert box["commit"] == curve.to_affine(curve.scalar_mul(curve.G1_GEN, P.poly_eval(v[:64], 99)))
+
+
 # ------------------------------------------------------------------ MSM / SRS / commit
 def test_msm_kats_and_edges(ctx):
     """curve.rs:535-544 and the degenerate inputs."""
@@ -213,6 +270,14 @@ def test_srs_upload_roundtrip(ctx):
     assert pa.Commitment.commit(sc, srs).point == curve.to_affine(curve.msm(pts, sc))
     with pytest.raises(pa.PlonkError):
         pa.Srs.from_points([(1, 2)])  # not on the curve
+    # every point is checked, not a sample: one bad point in the middle of a long SRS
+    for pos in (10, 1234):
+        bad = list(P.Srs(777, 20).g1_powers) * 100
+        x, y = bad[pos]
+        bad[pos] = (x, (y + 1) % curve.Q_MOD)
+        with pytest.raises(pa.PlonkError) as ei:
+            pa.Srs.from_points(bad)
+        assert "not on the curve" in str(ei.value)
 
 
 @pytest.mark.parametrize("log_n", [14, 16])
