@@ -241,6 +241,17 @@ int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_
 int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_inputs, size_t n_public_inputs,
                                plonk_fr out[6]);
 
+/* ---- benchmark input (host only, no device work; no counterpart in the reference): the synthetic
+ * 2^log_n-gate circuit the throughput figures are quoted on -- alternating a*b = c / a+b = c gates
+ * chained by the copy constraints a[i+1] = c[i], values from splitmix64 streams seeded by log_n.
+ * Fills n = 2^log_n Montgomery Fr per vector: wire values, the five selector vectors
+ * (constraint.rs:385-393), the S_sigma evaluation vectors Permutation::compute (permutation.rs:
+ * 55-140) yields for these copy constraints; and the eleven blinding scalars, the SRS trapdoor and
+ * the coset generators k1, k2 (permutation.rs:307-326).  log_n in [2, 26]. */
+int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_fr* c, plonk_fr* q_m, plonk_fr* q_l,
+                                plonk_fr* q_r, plonk_fr* q_o, plonk_fr* q_c, plonk_fr* s_sigma1, plonk_fr* s_sigma2,
+                                plonk_fr* s_sigma3, plonk_fr blinding[11], plonk_fr* tau, plonk_fr* k1, plonk_fr* k2);
+
 /* ---- measurement helper: achieved Fr / Fq Montgomery multiplications per second of a
  * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
  * priced against).  which: 0 = Fr, 1 = Fq in the 29-bit-limb lazy form the kernels multiply in;

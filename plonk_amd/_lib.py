@@ -104,6 +104,7 @@ SIGNATURES = {
     "plonk_fr_from_bytes": (_i32, [_vp, _vp]),
     "plonk_proof_serialize": (_i32, [_vp, _vp]),
     "plonk_proof_challenges": (_i32, [_vp, _vp, _sz, _vp]),
+    "plonk_synthetic_circuit": (_i32, [_u32] + [_vp] * 15),
     "plonk_bench_field_mul": (_i32, [_vp, _u32, C.POINTER(C.c_double)]),
     "plonk_timer_start": (_i32, [_vp]),
     "plonk_timer_stop": (_i32, [_vp, C.POINTER(C.c_double)]),

@@ -196,10 +196,19 @@ class SyntheticCircuit:
     the SRS trapdoor from splitmix64(SRS_SEED+k).  sigma is written in closed form: the classes
     {a[i+1], c[i]} become the 2-cycles a[i+1] <-> c[i] of Permutation::compute."""
 
-    def __init__(self, k):
-        rng = SplitMix64(SYNTH_SEED + k)
+    def __init__(self, k, native=None):
+        """native: generate with the library's host routine (plonk_synthetic_circuit) -- vectors are then
+        (n, 4) uint64 arrays of Montgomery limbs instead of lists of ints; the default picks it from 2^17
+        gates up, where the Python loop below takes long."""
         n = 1 << k
         self.k, self.n = k, n
+        self.public_input_positions = []
+        if native is None:
+            native = k >= 17
+        if native:
+            self._native(k)
+            return
+        rng = SplitMix64(SYNTH_SEED + k)
         a = [0] * n
         b = [0] * n
         c = [0] * n
@@ -225,4 +234,22 @@ class SyntheticCircuit:
         self.sigmas = ([powers[0]] + [self.k2 * powers[i - 1] % R_MOD for i in range(1, n)],
                        [self.k1 * powers[i] % R_MOD for i in range(n)],
                        [powers[i + 1] for i in range(n - 1)] + [self.k2 * powers[n - 1] % R_MOD])
-        self.public_input_positions = []
+
+    def _native(self, k):
+        import ctypes as C
+        import numpy as np
+        from . import _lib
+        from .api import _fr_value
+        n = self.n
+        vecs = [np.empty((n, 4), dtype=np.uint64) for _ in range(11)]
+        bl = (_lib.Fr * 11)()
+        tau, k1, k2 = _lib.Fr(), _lib.Fr(), _lib.Fr()
+        rc = _lib.lib.plonk_synthetic_circuit(k, *[v.ctypes.data_as(C.c_void_p) for v in vecs], bl, C.byref(tau),
+                                              C.byref(k1), C.byref(k2))
+        if rc != 0:
+            raise _lib.PlonkError(rc, "plonk_synthetic_circuit(%d)" % k)
+        self.wires = tuple(vecs[0:3])
+        self.selectors = tuple(vecs[3:8])
+        self.sigmas = tuple(vecs[8:11])
+        self.blinding = [_fr_value(x) for x in bl]
+        self.tau, self.k1, self.k2 = _fr_value(tau), _fr_value(k1), _fr_value(k2)

@@ -7,6 +7,8 @@
 #include "prover.hpp"
 
 namespace plonk {
+void synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_fr* c, plonk_fr* const sel[5], plonk_fr* const sig[3],
+                       plonk_fr blinding[11], plonk_fr* tau, plonk_fr* k1_out, plonk_fr* k2_out);
 double bench_field_mul(Ctx* ctx, uint32_t which);
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
                    size_t batch_stride);
@@ -542,6 +544,26 @@ int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_
     for (int k = 7; k < 9; ++k, p += 48)
         if (plonk_g1_decompress(p, g[k]) != PLONK_OK) return PLONK_E_INVALID;
     *proof = pr;
+    return PLONK_OK;
+}
+
+int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_fr* c, plonk_fr* q_m, plonk_fr* q_l, plonk_fr* q_r,
+                                plonk_fr* q_o, plonk_fr* q_c, plonk_fr* s_sigma1, plonk_fr* s_sigma2, plonk_fr* s_sigma3,
+                                plonk_fr blinding[11], plonk_fr* tau, plonk_fr* k1, plonk_fr* k2) {
+    plonk_fr* const sel[5] = {q_m, q_l, q_r, q_o, q_c};
+    plonk_fr* const sig[3] = {s_sigma1, s_sigma2, s_sigma3};
+    if (!a || !b || !c || !blinding || !tau || !k1 || !k2) return PLONK_E_INVALID;
+    for (auto p : sel)
+        if (!p) return PLONK_E_INVALID;
+    for (auto p : sig)
+        if (!p) return PLONK_E_INVALID;
+    try {
+        synthetic_circuit(log_n, a, b, c, sel, sig, blinding, tau, k1, k2);
+    } catch (const plonk::Error& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return PLONK_E_INTERNAL;
+    }
     return PLONK_OK;
 }
 

@@ -136,6 +136,25 @@ def test_compact_proof_json_round_trip():
         api.Proof.from_bytes(bytes(bad))
 
 
+def test_native_synthetic_circuit_matches_the_oracle():
+    """plonk_synthetic_circuit (host C++, what the 2^20 / 2^24-gate runs use) against the oracle's
+    generator and its union-find permutation, and against the Python generator of circuits.py."""
+    from plonk_amd import api, circuits
+    from oracle import fft as offt
+    for k in (2, 4, 9):
+        nat = circuits.SyntheticCircuit(k, native=True)
+        py = circuits.SyntheticCircuit(k, native=False)
+        cs, bl = P.synthetic_circuit(k)
+        perm = P.Permutation(cs, offt.Domain(cs.n))
+        assert [api.fr_from_array(w) for w in nat.wires] == [list(w) for w in cs.wire_values()] == [list(w) for w in py.wires]
+        assert [api.fr_from_array(q) for q in nat.selectors] == [list(q) for q in cs.selectors()]
+        assert [api.fr_from_array(s) for s in nat.sigmas] == [perm.s_sigma1_evals, perm.s_sigma2_evals, perm.s_sigma3_evals]
+        assert [api.fr_from_array(s) for s in nat.sigmas] == [list(s) for s in py.sigmas]
+        assert nat.blinding == bl == py.blinding
+        assert nat.tau == P.synthetic_tau(k) == py.tau
+        assert (nat.k1, nat.k2) == (perm.k1, perm.k2) == (py.k1, py.k2)
+
+
 def test_no_gpu_fails_loudly():
     """Without a HIP device the product must raise, never fall back to a CPU path."""
     import torch

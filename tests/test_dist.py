@@ -78,14 +78,14 @@ def test_sharded_commit_exchange_gloo(tmp_path):
 
 
 GPU_WORKER = r'''
-import json, os, sys
+import hashlib, json, os, sys
 sys.path.insert(0, %(root)r)
 import torch.distributed as dist
 import plonk_amd as pa
 from plonk_amd import circuits, sharded
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-k = 16
+k = int(os.environ["PLONK_TEST_LOG_N"])
 circ = circuits.SyntheticCircuit(k)
 n = circ.n
 ctx = pa.Context(0)   # both ranks share the one GPU of the test box
@@ -98,8 +98,11 @@ proof = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi))
 calls, nbytes = comm.stats()
 assert calls == 1 + 9, calls   # the coverage check, then one all-gather per commitment MSM
 assert comm.host.calls == calls
-want = [e for e in json.load(open(os.path.join(%(root)r, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
-assert proof.to_bytes().hex() == want["proof"], "sharded proof differs from the single-device golden proof"
+if k == 16:
+    want = [e for e in json.load(open(os.path.join(%(root)r, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
+    assert proof.to_bytes().hex() == want["proof"], "sharded proof differs from the single-device golden proof"
+else:   # the digest test_prove_full_size_verifies pins for the single-device proof of this circuit
+    assert k == 20 and hashlib.sha256(proof.to_bytes()).hexdigest()[:16] == "8b3f972755329b78"
 # slices that do not tile the point range are refused on every rank (the single-device prover
 # returns PLONK_E_INVALID for a polynomial past the SRS; a gap would silently drop coefficients)
 bad = pa.Srs.from_tau_range(circ.tau, lo + (1 if rank else 0), hi, ctx=ctx)
@@ -126,15 +129,18 @@ import pytest
 
 
 @pytest.mark.gpu
-def test_sharded_prove_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("k", [16, 20])
+def test_sharded_prove_two_ranks_one_gpu(tmp_path, k):
     """plonk_prove_3wire_sharded with world_size 2 (gloo for the exchange, both ranks on cuda:0):
-    every rank's SRS slice gets its own window table, the per-rank partial commitments are
-    all-gathered through the C callback, and both ranks emit the golden 2^16 proof."""
+    every rank's SRS slice gets its own window table, the ranks' shares of every MSM are all-gathered
+    (staged through the C callback), and both ranks emit the single-device proof: the golden 2^16
+    bytes, the pinned digest of the 2^20-gate benchmark configuration."""
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER % {"root": ROOT})
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29537 + k),
+                   PLONK_TEST_LOG_N=str(k))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
