@@ -86,6 +86,8 @@ int32_t plonk_dev_download(plonk_ctx* ctx, void* dst_host, const void* src_dev, 
  * would allow 32; 2^27, the 8n domain of a 2^24-gate circuit, is the largest size exercised). */
 int32_t plonk_ntt_dev(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags,
                       const plonk_fr* shift, uint32_t batch, size_t stride);
+/* Passes over HBM (kernel launches) a transform of 2^log_n elements takes; 0 for a size out of range. */
+uint32_t plonk_ntt_sweeps(uint32_t log_n);
 /* Same over a host buffer (upload, transform, download). */
 int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t flags,
                   const plonk_fr* shift, uint32_t batch, size_t stride);
@@ -218,6 +220,10 @@ typedef struct plonk_msm_timing {
  * plonk_msm_set_timing(ctx, 1) and plonk_msm_set_timing(ctx, 0). */
 int32_t plonk_msm_set_timing(plonk_ctx* ctx, int32_t enable);
 int32_t plonk_msm_last_timing(plonk_ctx* ctx, plonk_msm_timing* out);
+/* Device time of the fused quotient kernel (the loop of prover.rs:415-457 alone, without the
+ * transforms around it) of the last plonk_quotient_3wire_dev / plonk_prove_3wire* call made on this
+ * context while plonk_msm_set_timing was on. */
+int32_t plonk_quotient_last_timing(plonk_ctx* ctx, double* elapsed_ms);
 
 /* ---- encodings (host only, no device work) ---- */
 /* G1Affine::to_compressed_bytes (curve.rs:84-88). */
@@ -255,7 +261,8 @@ int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_
 /* ---- measurement helper: achieved Fr / Fq Montgomery multiplications per second of a
  * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
  * priced against).  which: 0 = Fr, 1 = Fq in the 29-bit-limb lazy form the kernels multiply in;
- * 2 = Fr, 3 = Fq in the saturated 32-bit-limb form. */
+ * 2 = Fr, 3 = Fq in the saturated 32-bit-limb form; 4 = the raw issue rate of v_mad_u64_u32 in
+ * lane-operations per second (a 29-bit-limb Fr / Fq product is at least 162 / 392 of them). */
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second);
 /* HIP-event stopwatch on the ctx stream (the stream every kernel of this ctx runs on): start
  * records an event, stop records a second one, waits for it and returns the elapsed device

@@ -68,6 +68,7 @@ SIGNATURES = {
     "plonk_dev_upload": (_i32, [_vp, _vp, _vp, _sz]),
     "plonk_dev_download": (_i32, [_vp, _vp, _vp, _sz]),
     "plonk_ntt_dev": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _sz]),
+    "plonk_ntt_sweeps": (_u32, [_u32]),
     "plonk_ntt": (_i32, [_vp, _vp, _u32, _u32, _vp, _u32, _sz]),
     "plonk_ntt_dev_noalloc": (_i32, [_vp, _vp, _u32, _u32, _vp]),
     "plonk_ntt_noalloc_max_log_n": (_u32, []),
@@ -97,6 +98,7 @@ SIGNATURES = {
     "plonk_msm_window_bits": (_u32, [_sz]),
     "plonk_msm_set_timing": (_i32, [_vp, _i32]),
     "plonk_msm_last_timing": (_i32, [_vp, C.POINTER(MsmTiming)]),
+    "plonk_quotient_last_timing": (_i32, [_vp, C.POINTER(C.c_double)]),
     "plonk_g1_compress": (_i32, [_vp, _vp]),
     "plonk_g1_decompress": (_i32, [_vp, _vp]),
     "plonk_proof_deserialize": (_i32, [_vp, _vp]),

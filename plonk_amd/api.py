@@ -165,6 +165,11 @@ class Context:
         return {"sort_ms": t.sort_ms, "big_bucket_ms": t.big_bucket_ms, "bucket_ms": t.bucket_ms, "reduce_ms": t.reduce_ms,
                 "entries": t.entries, "window_bits": t.window_bits, "bucket_sets": t.bucket_sets}
 
+    def quotient_last_timing(self):
+        v = C.c_double()
+        self.check(lib.plonk_quotient_last_timing(self.h, C.byref(v)))
+        return v.value
+
     def bench_field_mul(self, which):
         v = C.c_double()
         self.check(lib.plonk_bench_field_mul(self.h, which, C.byref(v)))

@@ -73,8 +73,53 @@ static double run_bench(Ctx* ctx) {
     return muls / (best * 1e-3);
 }
 
+// Raw issue rate of v_mad_u64_u32 (the instruction the 29-bit-limb products are made of): 8
+// independent accumulators per lane, lane-operations per second.
+__global__ __launch_bounds__(256) void mad_rate_kernel(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t a[8], b[8];
+    uint64_t w[8];
+    for (int i = 0; i < 8; ++i) {
+        a[i] = threadIdx.x * 2654435761u + i * 40503u + seed;
+        b[i] = a[i] ^ 0x9e3779b9u;
+        w[i] = ((uint64_t)a[i] << 32) | b[i];
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
+        }
+    }
+    uint32_t acc = 0;
+    for (int i = 0; i < 8; ++i) acc ^= (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+static double run_mad_rate(Ctx* ctx) {
+    const int blocks = 256 * 8, threads = 256, iters = 2000;
+    DevBuf<uint32_t> out((size_t)blocks * threads);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mad_rate_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, out.p, 10, 1u);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(mad_rate_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, out.p, iters, 2u + rep);
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)blocks * threads * iters * 32.0 / (best * 1e-3);
+}
+
 double bench_field_mul(Ctx* ctx, uint32_t which) {
     switch (which) {
+        case 4: return run_mad_rate(ctx);
         case 0: return run_bench<LazyMul<FrX>>(ctx);
         case 1: return run_bench<LazyMul<FqX>>(ctx);
         case 2: return run_bench<SatMul<FrP>>(ctx);

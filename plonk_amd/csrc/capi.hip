@@ -172,6 +172,14 @@ int32_t plonk_ntt_dev_noalloc(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n
 
 uint32_t plonk_ntt_noalloc_max_log_n(void) { return ntt_noalloc_max_log_n(); }
 
+uint32_t plonk_ntt_sweeps(uint32_t log_n) {
+    try {
+        return log_n <= 28 ? ntt_sweeps(log_n) : 0;
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
 int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t flags, const plonk_fr* shift,
                   uint32_t batch, size_t stride) {
     if (!ctx) return PLONK_E_INVALID;
@@ -439,6 +447,18 @@ int32_t plonk_msm_set_timing(plonk_ctx* ctx, int32_t enable) {
     if (!ctx) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     msm_set_timing(C_, enable != 0);
+    C_->kernel_timing = enable != 0;
+    API_END()
+}
+
+int32_t plonk_quotient_last_timing(plonk_ctx* ctx, double* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    PLONK_REQUIRE(C_->q_timed && C_->q_ev1, "quotient timing: no timed quotient evaluation has run on this context");
+    HIP_CHECK(hipEventSynchronize(C_->q_ev1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, C_->q_ev0, C_->q_ev1));
+    *elapsed_ms = ms;
     API_END()
 }
 
@@ -568,7 +588,7 @@ int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_
 }
 
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second) {
-    if (!ctx || !muls_per_second || which > 3) return PLONK_E_INVALID;
+    if (!ctx || !muls_per_second || which > 4) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     *muls_per_second = bench_field_mul(C_, which);
     API_END()

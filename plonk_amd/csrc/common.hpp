@@ -64,6 +64,8 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;               // plonk_timer_start / _stop
+    hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;           // around the last quotient kernel (while MSM timing is on)
+    bool kernel_timing = false, q_timed = false;
     std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9
     DevBuf<fr_t> ntt_tmp;                                  // intermediate image of a multi-pass NTT
     bool ntt_lds_attr_set = false;                         // dynamic-LDS limit of ntt_pass_kernel raised
@@ -92,6 +94,7 @@ void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, ui
 NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags);
 void ntt_noalloc_init(int device);
 uint32_t ntt_noalloc_max_log_n();
+uint32_t ntt_sweeps(uint32_t log_n);
 void ntt_run_noalloc(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift);
 
 }  // namespace plonk

@@ -298,6 +298,8 @@ Ctx::~Ctx() {
     ntt_tmp.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (q_ev0) (void)hipEventDestroy(q_ev0);
+    if (q_ev1) (void)hipEventDestroy(q_ev1);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -523,6 +525,13 @@ void ntt_noalloc_init(int device) {
 }
 
 uint32_t ntt_noalloc_max_log_n() { return NOALLOC_MAX_LOG_N; }
+
+// passes over HBM a transform of 2^log_n elements takes
+uint32_t ntt_sweeps(uint32_t log_n) {
+    NttPlan pl;
+    plan_geometry(&pl, log_n, 0);
+    return pl.n_pass;
+}
 
 // One vector of 2^log_n elements, in place, on ctx->stream.  The static workspace keeps the tables
 // of the last (log_n, flags, shift) it was used with; another combination regenerates them by a

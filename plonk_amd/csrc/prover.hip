@@ -198,8 +198,17 @@ void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr
     for (int r = 0; r < 4; ++r) q.zh_inv[r] = to_frx(pk->zh_inv[r]);
     q.n4 = n4;
     q.log_l = pk->log_lx;
+    ctx->q_timed = ctx->kernel_timing;
+    if (ctx->q_timed) {
+        if (!ctx->q_ev0) {
+            HIP_CHECK(hipEventCreate(&ctx->q_ev0));
+            HIP_CHECK(hipEventCreate(&ctx->q_ev1));
+        }
+        HIP_CHECK(hipEventRecord(ctx->q_ev0, ctx->stream));
+    }
     hipLaunchKernelGGL(quotient_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, q);
     HIP_CHECK(hipGetLastError());
+    if (ctx->q_timed) HIP_CHECK(hipEventRecord(ctx->q_ev1, ctx->stream));
 }
 
 // plonk_quotient_3wire_dev: coset NTTs of the wire polynomials, fused evaluation, coset iNTT.
