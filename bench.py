@@ -125,8 +125,21 @@ def launch_ranks(n_ranks):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    import threading
+    box = {}
+    reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()))
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):   # a rank died: the others would wait for it in a collective
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    reader.join()
+    out0 = box.get("out", b"")
     lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
     if any(codes) or not lines:
         sys.stderr.write("bench.py: rank exit codes %r; rank 0 printed %d JSON line(s)\n" % (codes, len(lines)))
@@ -203,6 +216,12 @@ def main():
     ms = dt / args.steps * 1e3
     digest = __import__("hashlib").sha256(proof.to_bytes()).hexdigest()[:16]
 
+    # one more proof with the event marks on, on every rank (a sharded proof is a collective): the quotient kernel alone
+    ctx.msm_set_timing(True)
+    prover.prove([], circ.blinding)
+    quot_ms = ctx.quotient_last_timing()
+    ctx.msm_set_timing(False)
+
     out = None
     if rank == 0:
         # ---- stand-alone kernel rates on this GPU (after the timed region) ----
@@ -232,8 +251,6 @@ def main():
             phases.append(ctx.msm_last_timing())   # HIP events on the streams the MSM kernels run on
         msm_s = (time.perf_counter() - t1) / 5
         ctx.free(sc)
-        prover.prove([], circ.blinding)            # one more proof with the event marks on: the quotient kernel alone
-        quot_ms = ctx.quotient_last_timing()
         ctx.msm_set_timing(False)
         fq_peak = ctx.bench_field_mul(1)
         fr_peak = ctx.bench_field_mul(0)

@@ -88,9 +88,11 @@ inline host::fr_h to_host(const fr_t& d) {
 // ntt.hip
 constexpr uint32_t NTT_INVERSE = PLONK_NTT_INVERSE;
 constexpr uint32_t NTT_COSET = PLONK_NTT_COSET;
-void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride);
+// in_len: every vector is zero from that index on (a zero-padded coefficient vector); the first sweep then
+// neither reads nor scales the padding, which may hold anything.  0 = the whole vector is input.
+void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride, size_t in_len = 0);
 void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
-                size_t batch_stride);
+                size_t batch_stride, size_t in_len = 0);
 NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags);
 void ntt_noalloc_init(int device);
 uint32_t ntt_noalloc_max_log_n();

@@ -261,6 +261,26 @@ template <class X>
 __device__ __forceinline__ xe_t<X> x_canon2(const xe_t<X>& a) {
     return x_csub<X, 1>(a);
 }
+// ... of a normalised Fr value below 64p, without a Montgomery product: the top limb (the value's bits from
+// 232 up, below 2^29) estimates the quotient by p, one pass subtracts that multiple of p and one
+// conditional subtraction finishes.  With p / 2^232 = 7597479.16 and M = floor(2^40 / 7597480) the estimate
+// q = (top * M) >> 40 satisfies x / p - 1 < q <= x / p for every x below 64p, so x - q p lies in [0, 2p).
+__device__ __forceinline__ xe_t<FrX> frx_canon64(const xe_t<FrX>& a) {
+    constexpr uint64_t M = ((uint64_t)1 << 40) / 7597480u;
+    const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * M) >> 40);
+    xe_t<FrX> r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc += (int64_t)a.l[k] - (int64_t)((uint64_t)q * FrX::p(k));
+        r.l[k] = (uint32_t)acc & XMASK;
+        acc >>= 29;
+    }
+    acc += (int64_t)a.l[8] - (int64_t)((uint64_t)q * FrX::p(8));
+    r.l[8] = (uint32_t)acc;
+    return x_csub<FrX, 1>(r);
+}
+
 template <class X>
 __device__ __forceinline__ bool x_is_zero16(const xe_t<X>& a) {
     // a normalised value below 16p is 0 mod p only if it is k p with k < 16, and then its low limb

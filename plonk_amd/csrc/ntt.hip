@@ -24,9 +24,9 @@
 namespace plonk {
 
 static constexpr int NTT_MAX_PASSES = 4;
-static constexpr int NTT_TILE_LOG = 10;      // elements per LDS tile (36 KiB of 9-limb elements)
+static constexpr int NTT_TILE_LOG = 11;      // elements per LDS tile (72 KiB of 9-limb elements)
 static constexpr int NTT_SUBTW_LOG = 11;     // sub_tw holds w_{2^11}^j, j < 2^10
-static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_THREADS = 512;
 
 // Arithmetic runs in the radix-2^29 lazy Montgomery form of fieldx.cuh.  The transform is linear, so
 // the saturated Montgomery words of an input are only regrouped into 29-bit limbs (the value read
@@ -50,6 +50,7 @@ struct NttPassArgs {
     uint32_t r_prev[NTT_MAX_PASSES];
     uint32_t is_last;
     uint64_t batch_stride;
+    uint64_t in_len;              // first sweep: elements from this index on are taken as zero and not read (0 = all are read)
 };
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -142,8 +143,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             d = e >> log_c;
             addr = ((size_t)hi << (R + p.log_s)) + ((size_t)d << p.log_s) + lo_base + c;
         }
-        frx x = x_repack_in<FrX>(ld(in + addr));
-        if (p.pre) x = x_mul<FrX>(x, ld_tw(p.pre + d));
+        frx x = x_zero<FrX>();
+        if (!p.in_len || addr < p.in_len) {   // a zero-padded coefficient vector: the padding costs neither a read nor a product
+            x = x_repack_in<FrX>(ld(in + addr));
+            if (p.pre) x = x_mul<FrX>(x, ld_tw(p.pre + d));
+        }
         tile_mem.put(lds_index(d, c), x);
     }
     __syncthreads();
@@ -231,8 +235,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
             const uint32_t K = digits_rev(hi_c, p.log_h, p.n_prev, p.r_prev);
             addr = (size_t)K + ((size_t)k << p.log_h);
-            if (!p.post) x = x_mul<FrX>(x, x_one<FrX>());   // below 2p, same residue
-            x = x_canon2<FrX>(x);   // the transform's output is canonical
+            // the transform's output is canonical: a product is below 2p; without one the element is a
+            // lazy sum below 64p
+            x = p.post ? x_canon2<FrX>(x) : frx_canon64(x);
         } else {
             // step twiddles: for every later sweep q the factor w_N^(k M_p * i_q S_q), i_q read off
             // the lower index (this is also what brings the element back below 2p)
@@ -306,10 +311,35 @@ Ctx::~Ctx() {
 static void plan_geometry(NttPlan* pl, uint32_t log_n, uint32_t flags) {
     pl->log_n = log_n;
     pl->flags = flags;
-    const uint32_t P = log_n <= NTT_TILE_LOG ? 1 : (log_n + 7) / 8;
-    PLONK_REQUIRE(P <= NTT_MAX_PASSES, "ntt: log_n out of range");
+    // One sweep up to the tile size; two up to 2^20 (tiles of at least two 32-byte columns); from there
+    // sweeps of 2^8, the last ones shortened -- by two stages at a time where possible: a sweep of an
+    // even number of stages runs them all in pairs, and the first pair of a sweep costs one product
+    // per four elements instead of four (measured on MI355X, coset transform: 2^22 as 8+8+6 0.605 ms,
+    // as 8+7+7 0.627 ms, as 11+11 -- single-column tiles, 32-byte accesses -- 0.756 ms).
+    uint32_t P;
+    if (log_n <= NTT_TILE_LOG) {
+        P = 1;
+        pl->R[0] = log_n;
+    } else if (log_n <= 2 * NTT_TILE_LOG - 2) {
+        P = 2;
+        pl->R[0] = (log_n + 1) / 2;
+        pl->R[1] = log_n / 2;
+    } else {
+        P = (log_n + 7) / 8;
+        PLONK_REQUIRE(P <= NTT_MAX_PASSES, "ntt: log_n out of range");
+        for (uint32_t p = 0; p < P; ++p) pl->R[p] = 8;
+        uint32_t excess = 8 * P - log_n;
+        for (uint32_t p = P; excess >= 2 && p-- > 1;) {
+            pl->R[p] -= 2;
+            excess -= 2;
+        }
+        for (uint32_t p = P; excess >= 2 && p-- > 1;) {   // a second round for the smallest sizes of a sweep count
+            pl->R[p] -= 2;
+            excess -= 2;
+        }
+        if (excess) pl->R[1] -= excess;   // 0 or 1 left
+    }
     pl->n_pass = P;
-    for (uint32_t p = 0; p < P; ++p) pl->R[p] = log_n / P + (p < log_n % P ? 1 : 0);
 }
 
 // 48-byte slots the tables of a plan take
@@ -418,7 +448,7 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
 // `tmp`: the intermediate image of a multi-sweep transform (as large as the strided batch); unused
 // when the plan has one sweep.
 static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride,
-                       fr_t* tmp) {
+                       fr_t* tmp, size_t in_len = 0) {
     const uint32_t log_n = pl->log_n, P = pl->n_pass;
     if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
     if (!ctx->ntt_lds_attr_set) {   // per device, and a context belongs to one device
@@ -457,6 +487,7 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         for (uint32_t q = 0; q < p; ++q) a.r_prev[q] = pl->R[q];
         a.is_last = last ? 1u : 0u;
         a.batch_stride = batch_stride;
+        a.in_len = (p == 0 && in_len < ((size_t)1 << log_n)) ? in_len : 0;
         uint32_t log_c = NTT_TILE_LOG > R ? NTT_TILE_LOG - R : 0;
         if (last) log_c = p ? std::min(log_c, pl->R[0]) : 0u;
         else log_c = std::min(log_c, log_s);
@@ -477,16 +508,16 @@ static fr_t* ctx_tmp(Ctx* ctx, const NttPlan* pl, uint32_t batch, size_t batch_s
     return ctx->ntt_tmp.p;
 }
 
-void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride) {
-    ntt_run_on(ctx, ctx->stream, data_dev, log_n, flags, batch, batch_stride);
+void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch, size_t batch_stride, size_t in_len) {
+    ntt_run_on(ctx, ctx->stream, data_dev, log_n, flags, batch, batch_stride, in_len);
 }
 
 // The same on another stream of the context.  The sweeps share one scratch buffer per context: the
 // caller orders this stream against every other transform of the context.
 void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
-                size_t batch_stride) {
+                size_t batch_stride, size_t in_len) {
     NttPlan* pl = ntt_get_plan(ctx, log_n, flags);
-    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride));
+    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride), in_len);
 }
 
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,

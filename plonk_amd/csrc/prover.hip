@@ -135,10 +135,9 @@ Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plon
     // evaluations -> coefficients (preprocess.rs:115-127)
     ntt_run(ctx, pk->coef.p, log_n, NTT_INVERSE, 9, n);
     // coefficients -> evaluations on the 4n coset 7*H (what prover.rs:380-392 does per proof)
-    HIP_CHECK(hipMemsetAsync(pk->ext.p, 0, 9 * n4 * sizeof(fr_t), st));
     HIP_CHECK(hipMemcpy2DAsync(pk->ext.p, n4 * sizeof(fr_t), pk->coef.p, n * sizeof(fr_t), n * sizeof(fr_t), 9,
                                hipMemcpyDeviceToDevice, st));
-    ntt_run(ctx, pk->ext.p, log_n + 2, NTT_COSET, 9, n4);
+    ntt_run(ctx, pk->ext.p, log_n + 2, NTT_COSET, 9, n4, n);   // rows hold n coefficients; the rest of a row is never read
     // the quotient kernel's scaling of the selector rows (see QuotientArgs)
     hipLaunchKernelGGL(scale_rows_kernel, dim3((uint32_t)((n4 + 255) / 256)), dim3(256), 0, st, pk->ext.p, n4,
                        to_dev(Fr::from_u64(1024)));
@@ -390,9 +389,9 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     for (size_t i = 0; i < n_pub; ++i) tr.absorb_fr("pi_" + std::to_string(i), pi[i]);  // :69-71
 
     HIP_CHECK(hipMemsetAsync(ws->flag.p, 0, 16, st));
-    // a, b, c, z: [0, n) is overwritten by the evaluations, the blinding lands on [n, n + 3), and the coset
-    // transform reads all 4n: only the tails have to start at zero
-    for (int k = 0; k < 4; ++k) HIP_CHECK(hipMemsetAsync(W[k] + n, 0, (n4 - n) * sizeof(fr_t), st));
+    // a, b, c, z: [0, n) is overwritten by the evaluations and the blinding is added onto [n, n + 3); the coset
+    // transforms are told the coefficient count and never read past it, so nothing else has to be zero
+    for (int k = 0; k < 4; ++k) HIP_CHECK(hipMemsetAsync(W[k] + n, 0, 4 * sizeof(fr_t), st));
     HIP_CHECK(hipMemsetAsync(ws->co.p, 0, 4 * ns * sizeof(fr_t), st));
     HIP_CHECK(hipMemsetAsync(ws->tp.p, 0, 3 * ns * sizeof(fr_t), st));
 
@@ -403,7 +402,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     host::G1AffineH comm[9];
     // the wires' evaluations on the 4n coset (round 3 reads them; they depend on no challenge) are
     // computed while the last commitment's reduction drains
-    const MsmFiller coset_abc = [&](hipStream_t s) { ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4); };
+    const MsmFiller coset_abc = [&](hipStream_t s) { ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4, n + 2); };
     // wire by wire: the device transforms and commits one wire while the next is prepared -- for a
     // host witness the pageable upload keeps the host busy staging meanwhile
     MsmBatch r1;
@@ -449,7 +448,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_copy(ctx, CO[3], W[3], n + 3);
     }
     comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard,
-                         [&](hipStream_t s) { ntt_run_on(ctx, s, W[3], log_n + 2, NTT_COSET, 1, 0); });
+                         [&](hipStream_t s) { ntt_run_on(ctx, s, W[3], log_n + 2, NTT_COSET, 1, 0, n + 3); });
     check_flag(ctx, ws);
     tr.absorb_g1("z_comm", comm[3]);
     const fr_h alpha = tr.squeeze_challenge("alpha");
@@ -459,13 +458,12 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     if (n_pub && !pk->pi_positions.empty()) {  // prover.rs:840-857
         std::vector<fr_h> pe(n, Fr::zero());
         for (size_t i = 0; i < pk->pi_positions.size() && i < n_pub; ++i) pe[pk->pi_positions[i]] = Fr::neg(pi[i]);
-        HIP_CHECK(hipMemsetAsync(W[4] + n, 0, (n4 - n) * sizeof(fr_t), st));
         HIP_CHECK(hipMemcpyAsync(W[4], pe.data(), n * sizeof(fr_t), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));
         ntt_run(ctx, W[4], log_n, NTT_INVERSE, 1, 0);
         has_pi = true;
     }
-    if (has_pi) ntt_run(ctx, W[4], log_n + 2, NTT_COSET, 1, 0);
+    if (has_pi) ntt_run(ctx, W[4], log_n + 2, NTT_COSET, 1, 0, n);
     quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
     ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
     poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
