@@ -247,6 +247,43 @@ int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_
 int32_t plonk_proof_challenges(const plonk_proof* proof, const plonk_fr* public_inputs, size_t n_public_inputs,
                                plonk_fr out[6]);
 
+/* ---- verifier and JSON wire format (host only, no device work) ---- */
+/* ark's G2Affine (curve.rs:40-48): x, y in Fq2 = c0 + c1 u, Montgomery limbs, + infinity flag. */
+typedef struct plonk_g2 {
+    uint64_t x_c0[6], x_c1[6], y_c0[6], y_c1[6];
+    uint8_t infinity;
+    uint8_t pad[7];
+} plonk_g2;
+/* VerificationKey (plonk/types.rs:42-69); public_input_positions travel beside it as an array. */
+typedef struct plonk_vk {
+    uint64_t n;
+    plonk_g1 q_m_comm, q_l_comm, q_r_comm, q_o_comm, q_c_comm, s_sigma1_comm, s_sigma2_comm, s_sigma3_comm;
+    plonk_fr omega, k1, k2;
+} plonk_vk;
+/* G2Affine::generator (curve.rs:250-254) and scalar multiplication in G2 -- what kzg.rs:86 needs for
+ * the verifier's half of the SRS, g2_tau = g2_generator * tau. */
+int32_t plonk_g2_generator(plonk_g2* out);
+int32_t plonk_g2_mul(const plonk_g2* p, const plonk_fr* k, plonk_g2* out);
+/* pairing_check (curve.rs:408-412): *equal = [e(p1, q1) == e(p2, q2)]. */
+int32_t plonk_pairing_check(const plonk_g1* p1, const plonk_g2* q1, const plonk_g1* p2, const plonk_g2* q2, int32_t* equal);
+/* The verification key of preprocess (preprocess.rs:130-178) from a device-resident proving key:
+ * the eight commitments (computed on the device), n, omega, k1, k2. */
+int32_t plonk_vk_from_pk(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, plonk_vk* out);
+/* Verifier::verify (plonk/verifier.rs:36-343) with the reference's pairing check (:309-314) against
+ * g2_tau = [tau]_2 (kzg.rs:34): *accepted = 1 or 0.  PLONK_E_INVALID for inputs the reference's types
+ * cannot hold: a point off the curve or outside the order-r subgroup, an unreduced scalar, n not a
+ * power of two, a position >= n. */
+int32_t plonk_verify_3wire(const plonk_vk* vk, const uint64_t* public_input_positions, size_t n_positions,
+                           const plonk_g2* g2_tau, const plonk_proof* proof, const plonk_fr* public_inputs,
+                           size_t n_public_inputs, int32_t* accepted);
+/* serde_json::to_string(&CompactProof::from(&proof)) (trace.rs:255-332; points as
+ * {"compressed","x","y"} curve.rs:418-434, scalars as {"full","short"} field.rs:294-308).  Writes at
+ * most cap bytes (no terminator) and the full length to *len; PLONK_E_INVALID if cap is too small. */
+int32_t plonk_proof_to_json(const plonk_proof* proof, char* out, size_t cap, size_t* len);
+/* serde_json::from_str::<CompactProof> then Proof: reads `compressed` of every point (validated as
+ * plonk_g1_decompress does) and `full` of every scalar; PLONK_E_INVALID on malformed input. */
+int32_t plonk_proof_from_json(const char* json, size_t len, plonk_proof* proof);
+
 /* ---- benchmark input (host only, no device work; no counterpart in the reference): the synthetic
  * 2^log_n-gate circuit the throughput figures are quoted on -- alternating a*b = c / a+b = c gates
  * chained by the copy constraints a[i+1] = c[i], values from splitmix64 streams seeded by log_n.

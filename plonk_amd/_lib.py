@@ -35,6 +35,17 @@ class G1(C.Structure):
     _fields_ = [("x", C.c_uint64 * 6), ("y", C.c_uint64 * 6), ("infinity", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
+class G2(C.Structure):
+    _fields_ = [("x_c0", C.c_uint64 * 6), ("x_c1", C.c_uint64 * 6), ("y_c0", C.c_uint64 * 6), ("y_c1", C.c_uint64 * 6),
+                ("infinity", C.c_uint8), ("pad", C.c_uint8 * 7)]
+
+
+class Vk(C.Structure):
+    _fields_ = [("n", C.c_uint64)] + [(k, G1) for k in ("q_m_comm", "q_l_comm", "q_r_comm", "q_o_comm", "q_c_comm",
+                                                        "s_sigma1_comm", "s_sigma2_comm", "s_sigma3_comm")] + \
+               [("omega", Fr), ("k1", Fr), ("k2", Fr)]
+
+
 class Proof(C.Structure):
     _fields_ = [("a_comm", G1), ("b_comm", G1), ("c_comm", G1), ("z_comm", G1), ("t_lo_comm", G1),
                 ("t_mid_comm", G1), ("t_hi_comm", G1),
@@ -106,6 +117,13 @@ SIGNATURES = {
     "plonk_fr_from_bytes": (_i32, [_vp, _vp]),
     "plonk_proof_serialize": (_i32, [_vp, _vp]),
     "plonk_proof_challenges": (_i32, [_vp, _vp, _sz, _vp]),
+    "plonk_g2_generator": (_i32, [_vp]),
+    "plonk_g2_mul": (_i32, [_vp, _vp, _vp]),
+    "plonk_pairing_check": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "plonk_vk_from_pk": (_i32, [_vp, _vp, _vp, _vp]),
+    "plonk_verify_3wire": (_i32, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, C.POINTER(_i32)]),
+    "plonk_proof_to_json": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "plonk_proof_from_json": (_i32, [C.c_char_p, _sz, _vp]),
     "plonk_synthetic_circuit": (_i32, [_u32] + [_vp] * 15),
     "plonk_bench_field_mul": (_i32, [_vp, _u32, C.POINTER(C.c_double)]),
     "plonk_timer_start": (_i32, [_vp]),

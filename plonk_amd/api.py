@@ -400,6 +400,26 @@ class Proof:
             raise PlonkError(rc, "plonk_proof_deserialize")
         return cls(raw)
 
+    def to_json(self):
+        """serde_json's text of CompactProof (trace.rs:255-332), produced by the library."""
+        cap = 8192
+        buf = C.create_string_buffer(cap)
+        ln = C.c_size_t()
+        rc = lib.plonk_proof_to_json(C.byref(self.raw), buf, cap, C.byref(ln))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_proof_to_json")
+        return buf.raw[:ln.value].decode()
+
+    @classmethod
+    def from_json(cls, text):
+        """Inverse of to_json (reads `compressed` of every point and `full` of every scalar)."""
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        raw = _lib.Proof()
+        rc = lib.plonk_proof_from_json(data, len(data), C.byref(raw))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_proof_from_json: malformed CompactProof")
+        return cls(raw)
+
     def to_compact(self):
         """The CompactProof JSON object of trace.rs:255-332: points as {compressed, x, y}
         (curve.rs:418-434: 0x-hex of the 48-byte compressed form and of the two big-endian
@@ -552,3 +572,95 @@ class Prover:
             ctx.check(lib.plonk_prove_3wire(ctx.h, self.pk.h, self.srs.h, _ptr(self.wires[0]), _ptr(self.wires[1]),
                                             _ptr(self.wires[2]), pis, len(public_inputs), bl, C.byref(raw)))
         return Proof(raw)
+
+
+def _g2_struct(pt):
+    g = _lib.G2()
+    if pt is None:
+        g.infinity = 1
+        return g
+    (x0, x1), (y0, y1) = pt
+    for name, v in (("x_c0", x0), ("x_c1", x1), ("y_c0", y0), ("y_c1", y1)):
+        m = v * _RQ % Q_MOD
+        arr = getattr(g, name)
+        for i in range(6):
+            arr[i] = (m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+    return g
+
+
+def _g2_value(g):
+    if g.infinity:
+        return None
+    val = lambda arr: sum(int(arr[i]) << (64 * i) for i in range(6)) * _RQ_INV % Q_MOD
+    return ((val(g.x_c0), val(g.x_c1)), (val(g.y_c0), val(g.y_c1)))
+
+
+def g2_generator():
+    """curve.rs:250-254."""
+    g = _lib.G2()
+    lib.plonk_g2_generator(C.byref(g))
+    return g
+
+
+def g2_mul(point, k):
+    """k * point in G2 (kzg.rs:86: g2_tau = g2_generator * tau); `point` a _lib.G2."""
+    out = _lib.G2()
+    ks = _fr_struct(k)
+    rc = lib.plonk_g2_mul(C.byref(point), C.byref(ks), C.byref(out))
+    if rc != 0:
+        raise PlonkError(rc, "plonk_g2_mul")
+    return out
+
+
+def pairing_check(p1, q1, p2, q2):
+    """curve.rs:408-412; p1, p2 affine (x, y) or None, q1, q2 _lib.G2."""
+    eq = C.c_int32()
+    a, b = _g1_struct(p1), _g1_struct(p2)
+    rc = lib.plonk_pairing_check(C.byref(a), C.byref(q1), C.byref(b), C.byref(q2), C.byref(eq))
+    if rc != 0:
+        raise PlonkError(rc, "plonk_pairing_check: invalid point")
+    return bool(eq.value)
+
+
+class VerificationKey:
+    """plonk/types.rs:42-69."""
+
+    def __init__(self, raw, public_input_positions=()):
+        self.raw = raw
+        self.public_input_positions = list(public_input_positions)
+
+    @classmethod
+    def from_proving_key(cls, pk, srs, public_input_positions=()):
+        """preprocess.rs:130-178: the eight commitments are computed on the device."""
+        raw = _lib.Vk()
+        pk.ctx.check(lib.plonk_vk_from_pk(pk.ctx.h, pk.h, srs.h, C.byref(raw)))
+        return cls(raw, public_input_positions)
+
+    @classmethod
+    def from_values(cls, n, commitments, omega, k1, k2, public_input_positions=()):
+        """commitments: q_m, q_l, q_r, q_o, q_c, s_sigma1, s_sigma2, s_sigma3 as affine (x, y) or None."""
+        raw = _lib.Vk()
+        raw.n = n
+        for name, pt in zip(("q_m_comm", "q_l_comm", "q_r_comm", "q_o_comm", "q_c_comm", "s_sigma1_comm", "s_sigma2_comm",
+                             "s_sigma3_comm"), commitments):
+            setattr(raw, name, _g1_struct(pt))
+        raw.omega, raw.k1, raw.k2 = _fr_struct(omega), _fr_struct(k1), _fr_struct(k2)
+        return cls(raw, public_input_positions)
+
+
+class Verifier:
+    """plonk/verifier.rs:24-40 -- Verifier::new(vk, srs) / verify(proof, public_inputs); of the SRS the
+    verifier needs g2_tau only (kzg.rs:34), a _lib.G2."""
+
+    def __init__(self, vk, g2_tau):
+        self.vk, self.g2_tau = vk, g2_tau
+
+    def verify(self, proof, public_inputs=()):
+        pos = (C.c_uint64 * max(len(self.vk.public_input_positions), 1))(*self.vk.public_input_positions)
+        pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])
+        ok = C.c_int32()
+        rc = lib.plonk_verify_3wire(C.byref(self.vk.raw), pos, len(self.vk.public_input_positions), C.byref(self.g2_tau),
+                                    C.byref(proof.raw), pis, len(public_inputs), C.byref(ok))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_verify_3wire: malformed verification key, proof or public input")
+        return bool(ok.value)

@@ -4,12 +4,18 @@
 
 #include "common.hpp"
 #include "msm.hpp"
+#include "pairing.hpp"
 #include "prover.hpp"
 
 namespace plonk {
 void synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_fr* c, plonk_fr* const sel[5], plonk_fr* const sig[3],
                        plonk_fr blinding[11], plonk_fr* tau, plonk_fr* k1_out, plonk_fr* k2_out);
 double bench_field_mul(Ctx* ctx, uint32_t which);
+int verify_3wire(const plonk_vk* vk, const uint64_t* pi_positions, size_t n_positions, const plonk_g2* g2_tau,
+                 const plonk_proof* pr, const plonk_fr* pub, size_t n_pub, bool* accepted);
+std::string proof_to_json(const plonk_proof* p);
+bool proof_from_json(const char* json, size_t len, plonk_proof* out);
+void g2_out(const host::G2AffineH& a, plonk_g2* p);
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
                    size_t batch_stride);
 }  // namespace plonk
@@ -565,6 +571,112 @@ int32_t plonk_proof_deserialize(const uint8_t in[PLONK_PROOF_WIRE_BYTES], plonk_
         if (plonk_g1_decompress(p, g[k]) != PLONK_OK) return PLONK_E_INVALID;
     *proof = pr;
     return PLONK_OK;
+}
+
+// ---- verifier / JSON (host only) ----
+static host::G2AffineH g2_from(const plonk_g2& p) {
+    host::G2AffineH a;
+    memcpy(a.x.c0.l, p.x_c0, 48);
+    memcpy(a.x.c1.l, p.x_c1, 48);
+    memcpy(a.y.c0.l, p.y_c0, 48);
+    memcpy(a.y.c1.l, p.y_c1, 48);
+    a.inf = p.infinity != 0;
+    return a;
+}
+static bool g2_ok(const host::G2AffineH& a) {
+    return a.inf || (!host::Fq::geq_p(a.x.c0) && !host::Fq::geq_p(a.x.c1) && !host::Fq::geq_p(a.y.c0) &&
+                     !host::Fq::geq_p(a.y.c1) && host::g2_on_curve(a));
+}
+static bool g1_ok(const plonk_g1& p, host::G1AffineH* out) {
+    memcpy(out->x.l, p.x, 48);
+    memcpy(out->y.l, p.y, 48);
+    out->inf = p.infinity != 0;
+    return out->inf || (!host::Fq::geq_p(out->x) && !host::Fq::geq_p(out->y) && host::g1_on_curve(*out));
+}
+
+int32_t plonk_g2_generator(plonk_g2* out) {
+    if (!out) return PLONK_E_INVALID;
+    g2_out(host::g2_generator(), out);
+    return PLONK_OK;
+}
+
+int32_t plonk_g2_mul(const plonk_g2* p, const plonk_fr* k, plonk_g2* out) {
+    if (!p || !k || !out) return PLONK_E_INVALID;
+    const host::G2AffineH a = g2_from(*p);
+    host::fr_h s;
+    memcpy(s.l, k->l, 32);
+    if (!g2_ok(a) || host::Fr::geq_p(s)) return PLONK_E_INVALID;
+    const host::fr_h c = host::Fr::from_mont(s);
+    g2_out(host::g2_mul_limbs(a, c.l, 4), out);
+    return PLONK_OK;
+}
+
+int32_t plonk_pairing_check(const plonk_g1* p1, const plonk_g2* q1, const plonk_g1* p2, const plonk_g2* q2, int32_t* equal) {
+    if (!p1 || !q1 || !p2 || !q2 || !equal) return PLONK_E_INVALID;
+    host::G1AffineH a, b;
+    const host::G2AffineH c = g2_from(*q1), d = g2_from(*q2);
+    if (!g1_ok(*p1, &a) || !g1_ok(*p2, &b) || !g2_ok(c) || !g2_ok(d)) return PLONK_E_INVALID;
+    *equal = host::pairing_check(a, c, b, d) ? 1 : 0;
+    return PLONK_OK;
+}
+
+int32_t plonk_vk_from_pk(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, plonk_vk* out) {
+    if (!ctx || !pk || !srs || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "vk: key or SRS lives on another device");
+    memset(out, 0, sizeof(*out));
+    out->n = k->n;
+    plonk_g1* dst[8] = {&out->q_m_comm, &out->q_l_comm, &out->q_r_comm, &out->q_o_comm, &out->q_c_comm,
+                        &out->s_sigma1_comm, &out->s_sigma2_comm, &out->s_sigma3_comm};
+    for (int q = 0; q < 8; ++q) g1_from_host(commit_checked(C_, s, k->coef.p + q * k->n, k->n), dst[q]);
+    memcpy(out->omega.l, k->omega.l, 32);
+    memcpy(out->k1.l, k->k1.l, 32);
+    memcpy(out->k2.l, k->k2.l, 32);
+    API_END()
+}
+
+int32_t plonk_verify_3wire(const plonk_vk* vk, const uint64_t* public_input_positions, size_t n_positions,
+                           const plonk_g2* g2_tau, const plonk_proof* proof, const plonk_fr* public_inputs,
+                           size_t n_public_inputs, int32_t* accepted) {
+    if (!vk || !g2_tau || !proof || !accepted || (n_positions && !public_input_positions) ||
+        (n_public_inputs && !public_inputs))
+        return PLONK_E_INVALID;
+    *accepted = 0;
+    try {
+        bool ok = false;
+        const int rc = verify_3wire(vk, public_input_positions, n_positions, g2_tau, proof, public_inputs, n_public_inputs, &ok);
+        if (rc != PLONK_OK) return rc;
+        *accepted = ok ? 1 : 0;
+    } catch (const std::bad_alloc&) {
+        return PLONK_E_NOMEM;
+    } catch (const std::exception&) {
+        return PLONK_E_INTERNAL;
+    }
+    return PLONK_OK;
+}
+
+int32_t plonk_proof_to_json(const plonk_proof* proof, char* out, size_t cap, size_t* len) {
+    if (!proof || !len || (cap && !out)) return PLONK_E_INVALID;
+    try {
+        const std::string s = proof_to_json(proof);
+        *len = s.size();
+        if (s.size() > cap) return PLONK_E_INVALID;
+        memcpy(out, s.data(), s.size());
+    } catch (const std::exception&) {
+        return PLONK_E_NOMEM;
+    }
+    return PLONK_OK;
+}
+
+int32_t plonk_proof_from_json(const char* json, size_t len, plonk_proof* proof) {
+    if (!json || !proof) return PLONK_E_INVALID;
+    try {
+        return proof_from_json(json, len, proof) ? PLONK_OK : PLONK_E_INVALID;
+    } catch (const std::exception&) {
+        return PLONK_E_NOMEM;
+    }
 }
 
 int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_fr* c, plonk_fr* q_m, plonk_fr* q_l, plonk_fr* q_r,

@@ -553,6 +553,15 @@ def test_prove_full_size_verifies(ctx):
     wire = pa.Proof.from_compact(proof.to_compact()).to_dict()
     assert P.verify_pairing(vk, g2_tau, wire, [])
     assert not P.verify_pairing(vk, g2_tau, bad, [])
+    # the library's own verifier (plonk_verify_3wire, pairing on the host) gives the same verdicts on the
+    # verification key it derives from the device-resident proving key
+    pvk = pa.VerificationKey.from_proving_key(pk, srs)
+    assert pa.api._g2_value(pa.g2_mul(pa.g2_generator(), circ.tau)) == g2_tau
+    ver = pa.Verifier(pvk, pa.g2_mul(pa.g2_generator(), circ.tau))
+    assert ver.verify(proof) and ver.verify(pa.Proof.from_json(proof.to_json()))
+    raw = pa._lib.Proof.from_buffer_copy(proof.raw)
+    raw.a_eval = pa.api._fr_struct(bad["a_eval"])
+    assert not ver.verify(pa.Proof(raw))
 
 
 def test_prove_largest_configuration(ctx):
