@@ -272,3 +272,27 @@ def test_compact_proof_json_from_the_library():
     raw.z_comm = pa.api._g1_struct(None)
     obj = json.loads(pa.Proof(raw).to_json())
     assert obj["round2"]["z"] == {"compressed": "0x" + curve.compress(None).hex(), "x": "infinity", "y": "infinity"}
+
+
+def test_rust_shim_declares_exactly_the_header():
+    """rust/plonk-hip-sys/src/lib.rs (source only: no Rust toolchain here) binds every entry point of
+    include/plonk_hip.h, no more and no fewer, with the same number of parameters."""
+    text = open(os.path.join(ROOT, "rust", "plonk-hip-sys", "src", "lib.rs")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    rust = {}
+    for m in re.finditer(r"pub fn (plonk_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", block, flags=re.S):
+        args = m.group(2).strip()
+        rust[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    header = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    c = {}
+    for m in re.finditer(r"\b(plonk_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;", header):
+        args = m.group(2).strip()
+        c[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    c.pop("plonk_allgather_fn", None)
+    assert sorted(rust) == sorted(c) == _declared()
+    assert rust == c
+    # struct sizes the Rust side mirrors
+    from plonk_amd import _lib
+    assert C.sizeof(_lib.G2) == 200 and C.sizeof(_lib.Vk) == 8 + 8 * 104 + 3 * 32
