@@ -16,8 +16,6 @@ int verify_3wire(const plonk_vk* vk, const uint64_t* pi_positions, size_t n_posi
 std::string proof_to_json(const plonk_proof* p);
 bool proof_from_json(const char* json, size_t len, plonk_proof* out);
 void g2_out(const host::G2AffineH& a, plonk_g2* p);
-void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
-                   size_t batch_stride);
 }  // namespace plonk
 
 using namespace plonk;

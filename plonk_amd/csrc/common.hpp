@@ -66,7 +66,7 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;               // plonk_timer_start / _stop
     hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;           // around the last quotient kernel (while MSM timing is on)
     bool kernel_timing = false, q_timed = false;
-    std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9
+    std::map<uint64_t, std::shared_ptr<NttPlan>> plans;   // key: log_n | inverse<<8 | coset<<9 | generator slot<<16
     DevBuf<fr_t> ntt_tmp;                                  // intermediate image of a multi-pass NTT
     bool ntt_lds_attr_set = false;                         // dynamic-LDS limit of ntt_pass_kernel raised
     std::shared_ptr<void> msm_ws;                          // MsmWorkspace (msm.hip)
@@ -94,6 +94,11 @@ void ntt_run(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t 
 void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, uint32_t batch,
                 size_t batch_stride, size_t in_len = 0);
 NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags);
+void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
+                   size_t batch_stride);
+// ... with any coset generator, on any stream of the context (same ordering duty as ntt_run_on)
+void ntt_run_shift_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift,
+                      uint32_t batch, size_t batch_stride);
 void ntt_noalloc_init(int device);
 uint32_t ntt_noalloc_max_log_n();
 uint32_t ntt_sweeps(uint32_t log_n);

@@ -425,19 +425,28 @@ static void plan_build_tables(NttPlan* pl, const host::fr_h& shift, frx_slot* me
     }
 }
 
-static uint64_t plan_key(uint32_t log_n, uint32_t flags) { return (uint64_t)log_n | ((uint64_t)(flags & 3u) << 8); }
+static constexpr uint32_t PLAN_SHIFT_SLOTS = 4;   // coset generators cached side by side per (size, direction)
+static uint64_t plan_key(uint32_t log_n, uint32_t flags, uint32_t slot) {
+    return (uint64_t)log_n | ((uint64_t)(flags & 3u) << 8) | ((uint64_t)slot << 16);
+}
 
 static NttPlan* get_plan_shift(Ctx* ctx, uint32_t log_n, uint32_t flags, const host::fr_h& shift) {
-    // plans are cached per (log_n, flags); a different coset shift rebuilds the entry
-    const uint64_t key = plan_key(log_n, flags);
-    auto it = ctx->plans.find(key);
-    if (it != ctx->plans.end() && (!(flags & NTT_COSET) || it->second->shift == shift)) return it->second.get();
+    // plans are cached per (log_n, flags) and, for coset transforms, per generator: a few side by side
+    // (the sharded prover uses one of its own beside 7), after that the first slot is rebuilt
+    const uint32_t slots = (flags & NTT_COSET) ? PLAN_SHIFT_SLOTS : 1;
+    uint32_t slot = 0;
+    for (; slot < slots; ++slot) {
+        auto it = ctx->plans.find(plan_key(log_n, flags, slot));
+        if (it == ctx->plans.end()) break;
+        if (!(flags & NTT_COSET) || it->second->shift == shift) return it->second.get();
+    }
+    if (slot == slots) slot = 0;
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // a replaced plan may still be in use
     std::shared_ptr<NttPlan> pl(new NttPlan());
     plan_geometry(pl.get(), log_n, flags);
     plan_build_tables(pl.get(), shift, nullptr, ctx->stream);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // other streams of the context may run the plan next
-    ctx->plans[key] = pl;
+    ctx->plans[plan_key(log_n, flags, slot)] = pl;
     return pl.get();
 }
 
@@ -522,8 +531,13 @@ void ntt_run_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, ui
 
 void ntt_run_shift(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift, uint32_t batch,
                    size_t batch_stride) {
+    ntt_run_shift_on(ctx, ctx->stream, data_dev, log_n, flags, shift, batch, batch_stride);
+}
+
+void ntt_run_shift_on(Ctx* ctx, hipStream_t stream, fr_t* data_dev, uint32_t log_n, uint32_t flags, const host::fr_h& shift,
+                      uint32_t batch, size_t batch_stride) {
     NttPlan* pl = get_plan_shift(ctx, log_n, flags, shift);
-    ntt_launch(ctx, ctx->stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride));
+    ntt_launch(ctx, stream, pl, data_dev, batch, batch_stride, ctx_tmp(ctx, pl, batch, batch_stride));
 }
 
 // ------------------------------------------------------------------------------------------

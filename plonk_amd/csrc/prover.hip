@@ -37,41 +37,48 @@ struct QuotientArgs {
     frx zh_inv[4];                    // true values; 1 / (x_i^n - 1) depends on i mod 4 only
     fr_t gamma, one;                  // saturated words (read as scaled values)
     uint32_t n4, log_l;
+    // The points this launch covers: i = (j << log_g) + q for j < count.  One GPU: log_g = 0, q = 0, count = 4n.
+    // A rank of a sharded proof holds the residue class q modulo G = 2^log_g of the coset: its vectors
+    // (wires, z, key tables, t) are indexed by j; zw holds z on the class of i + 4, whose element for j sits
+    // at (j + zw_off) mod count.
+    const fr_t* zw;
+    uint32_t log_g, q, count, zw_off;
 };
 
 __device__ __forceinline__ frx ld_scaled(const fr_t* p) { return x_repack_in<FrX>(ld(p)); }
 
 __global__ __launch_bounds__(256) void quotient_kernel(QuotientArgs q) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q.n4) return;
-    const size_t N = q.n4;
-    const frx a = ld_scaled(q.a + i), b = ld_scaled(q.b + i), c = ld_scaled(q.c + i), z = ld_scaled(q.z + i);
-    const frx zw = ld_scaled(q.z + ((i + 4) & (q.n4 - 1)));  // z(w X) on the 4n coset is a rotation by 4
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= q.count) return;
+    const size_t N = q.count;                    // row length of the key tables this launch reads
+    const uint32_t i = (j << q.log_g) + q.q;     // index of the point on the whole 4n coset
+    const frx a = ld_scaled(q.a + j), b = ld_scaled(q.b + j), c = ld_scaled(q.c + j), z = ld_scaled(q.z + j);
+    const frx zw = ld_scaled(q.zw + ((j + q.zw_off) & (q.count - 1)));  // z(w X) on the 4n coset is a rotation by 4
     frx x = ld_scaled(q.x_lo + (i & ((1u << q.log_l) - 1u)));
     if (i >> q.log_l) x = x_mul<FrX>(x, ld_tw(q.x_hi + (i >> q.log_l)));
     // gate: q_M a b + q_L a + q_R b + q_O c + q_C + PI   (each product below 2p, limbs normalised)
-    frx gate = x_mul<FrX>(x_mul<FrX>(ld_scaled(q.pk_ext + i), a), b);
-    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + N + i), a));
-    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 2 * N + i), b));
-    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 3 * N + i), c));
-    gate = x_add_lazy<FrX>(gate, ld_scaled(q.pk_ext + 4 * N + i));
-    if (q.pi) gate = x_add_lazy<FrX>(gate, ld_scaled(q.pi + i));
+    frx gate = x_mul<FrX>(x_mul<FrX>(ld_scaled(q.pk_ext + j), a), b);
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + N + j), a));
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 2 * N + j), b));
+    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 3 * N + j), c));
+    gate = x_add_lazy<FrX>(gate, ld_scaled(q.pk_ext + 4 * N + j));
+    if (q.pi) gate = x_add_lazy<FrX>(gate, ld_scaled(q.pi + j));
     // permutation: the three-term factors are sums of at most 4p with limbs below 2^31
     const frx gamma = x_repack_in<FrX>(q.gamma);
     const frx ag = x_add_lazy<FrX>(a, gamma), bg = x_add_lazy<FrX>(b, gamma), cg = x_add_lazy<FrX>(c, gamma);
     frx num = x_mul<FrX>(z, x_add_lazy<FrX>(ag, x_mul<FrX>(x, q.beta)));
     num = x_mul<FrX>(num, x_add_lazy<FrX>(bg, x_mul<FrX>(x, q.beta_k1)));
     num = x_mul<FrX>(num, x_add_lazy<FrX>(cg, x_mul<FrX>(x, q.beta_k2)));
-    frx den = x_mul<FrX>(zw, x_add_lazy<FrX>(ag, x_mul<FrX>(ld_scaled(q.pk_ext + 5 * N + i), q.beta)));
-    den = x_mul<FrX>(den, x_add_lazy<FrX>(bg, x_mul<FrX>(ld_scaled(q.pk_ext + 6 * N + i), q.beta)));
-    den = x_mul<FrX>(den, x_add_lazy<FrX>(cg, x_mul<FrX>(ld_scaled(q.pk_ext + 7 * N + i), q.beta)));
+    frx den = x_mul<FrX>(zw, x_add_lazy<FrX>(ag, x_mul<FrX>(ld_scaled(q.pk_ext + 5 * N + j), q.beta)));
+    den = x_mul<FrX>(den, x_add_lazy<FrX>(bg, x_mul<FrX>(ld_scaled(q.pk_ext + 6 * N + j), q.beta)));
+    den = x_mul<FrX>(den, x_add_lazy<FrX>(cg, x_mul<FrX>(ld_scaled(q.pk_ext + 7 * N + j), q.beta)));
     const frx perm = x_mul<FrX>(x_sub_lazy<FrX, 3>(num, den), q.alpha_32_3);     // three products deep: 2^-15
     const frx zm1 = x_sub_lazy<FrX, 3>(z, x_repack_in<FrX>(q.one));
-    const frx l1c = x_mul<FrX>(x_mul<FrX>(zm1, ld_scaled(q.pk_ext + 8 * N + i)), q.alpha2_32);
+    const frx l1c = x_mul<FrX>(x_mul<FrX>(zm1, ld_scaled(q.pk_ext + 8 * N + j)), q.alpha2_32);
     const frx numer = x_norm_u<FrX>(x_add_lazy<FrX>(gate, x_add_lazy<FrX>(perm, l1c)));   // 8 terms: limbs below 2^32
     const uint32_t r = i & 3u;
     const frx zi = r == 0 ? q.zh_inv[0] : (r == 1 ? q.zh_inv[1] : (r == 2 ? q.zh_inv[2] : q.zh_inv[3]));
-    st(q.t + i, x_repack_out<FrX>(x_canon2<FrX>(x_mul<FrX>(numer, zi))));
+    st(q.t + j, x_repack_out<FrX>(x_canon2<FrX>(x_mul<FrX>(numer, zi))));
 }
 
 // rows of the coset table times a constant (the 2^10 / 2^5 of q_M / q_L, q_R, q_O)
@@ -179,12 +186,20 @@ Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plon
     return pk.release();
 }
 
+// The residue class of the 4n coset one launch of the quotient kernel covers (see QuotientArgs).
+struct QuotientSlice {
+    uint32_t log_g = 0, q = 0;
+    const fr_t* ext = nullptr;   // key tables restricted to the class, [9][4n >> log_g]; null = the key's own tables
+    const fr_t* zw = nullptr;    // z on the class of i + 4; null = z itself
+    uint32_t zw_off = 4;
+};
+
 void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr_t* pi, const fr_h& alpha, const fr_h& beta,
-                  const fr_h& gamma, fr_t* t_out) {
+                  const fr_h& gamma, fr_t* t_out, const QuotientSlice& sl = QuotientSlice()) {
     const uint32_t n4 = (uint32_t)(4 * pk->n);
     QuotientArgs q;
     q.a = a; q.b = b; q.c = c; q.z = z; q.pi = pi;
-    q.pk_ext = pk->ext.p;
+    q.pk_ext = sl.ext ? sl.ext : pk->ext.p;
     q.x_lo = pk->x_lo.p; q.x_hi = pk->x_hi.p;
     q.t = t_out;
     q.alpha_32_3 = to_frx(Fr::mul(alpha, Fr::from_u64(32768)));
@@ -197,6 +212,11 @@ void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr
     for (int r = 0; r < 4; ++r) q.zh_inv[r] = to_frx(pk->zh_inv[r]);
     q.n4 = n4;
     q.log_l = pk->log_lx;
+    q.zw = sl.zw ? sl.zw : z;
+    q.log_g = sl.log_g;
+    q.q = sl.q;
+    q.count = n4 >> sl.log_g;
+    q.zw_off = sl.zw_off;
     ctx->q_timed = ctx->kernel_timing;
     if (ctx->q_timed) {
         if (!ctx->q_ev0) {
@@ -205,9 +225,61 @@ void quotient_run(Ctx* ctx, const Pk* pk, fr_t* a, fr_t* b, fr_t* c, fr_t* z, fr
         }
         HIP_CHECK(hipEventRecord(ctx->q_ev0, ctx->stream));
     }
-    hipLaunchKernelGGL(quotient_kernel, dim3((n4 + 255) / 256), dim3(256), 0, ctx->stream, q);
+    hipLaunchKernelGGL(quotient_kernel, dim3((q.count + 255) / 256), dim3(256), 0, ctx->stream, q);
     HIP_CHECK(hipGetLastError());
     if (ctx->q_timed) HIP_CHECK(hipEventRecord(ctx->q_ev1, ctx->stream));
+}
+
+// ---- round 3 sharded over the G = 2^g ranks of a proof (prover.rs:364-457, :497 split by evaluation point) ----
+// Rank q evaluates everything on the points x_i of the 4n coset with i = q mod G.  Those are the
+// coset s_q * H_M, M = 4n / G, s_q = 7 w_4n^q, of the subgroup of order M, so the evaluations of a polynomial f
+// there are ONE coset transform of size M of f mod (X^M - s_q^M) -- 1/G of the work, no exchange, every rank
+// holding all coefficient vectors.  The quotient is point-wise.  Its evaluations on the class give, by the
+// inverse coset transform of size M, F_q = t mod (X^M - c_q) with c_q = s_q^M = 7^M w_G^q:
+//     F_q[k] = sum_m t[k + m M] 7^(M m) w_G^(q m),
+// a DFT of length G across the ranks.  The F_q are all-gathered (4n field elements in all) and every rank
+// inverts that DFT: t[k + m M] = 7^(-M m) / G * sum_q w_G^(-q m) F_q[k].
+
+// out[k] = sum_m in[k + m M] c^m over the m with k + m M < len  (f mod (X^M - c))
+__global__ __launch_bounds__(256) void fold_kernel(const fr_t* __restrict__ in, uint32_t len, uint32_t M, fr_t c,
+                                                   fr_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    fr_t acc = k < len ? ld(in + k) : f_zero<FrP>();
+    fr_t pw = c;
+    for (uint32_t idx = k + M; idx < len; idx += M) {
+        acc = fr_add(acc, fr_mul(ld(in + idx), pw));
+        pw = fr_mul(pw, c);
+    }
+    st(out + k, acc);
+}
+
+// out[row][j] = in[row][(j << log_g) + q]
+__global__ __launch_bounds__(256) void class_gather_kernel(const fr_t* __restrict__ in, size_t in_stride, uint32_t log_g,
+                                                           uint32_t q, uint32_t M, fr_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const size_t row = blockIdx.y;
+    st(out + row * M + j, ld(in + row * in_stride + (((size_t)j << log_g) + q)));
+}
+
+// t[k + m M] = sum_q coef[m][q] F[q][k], m < G: the inverse DFT across the ranks with its scaling folded in
+static constexpr uint32_t SHARD_MAX_RANKS = 16;
+__global__ __launch_bounds__(256) void recombine_kernel(const fr_t* __restrict__ F, uint32_t G, uint32_t M,
+                                                        const fr_t* __restrict__ coef, fr_t* __restrict__ t) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    fr_t f[SHARD_MAX_RANKS];
+#pragma unroll
+    for (uint32_t q = 0; q < SHARD_MAX_RANKS; ++q)
+        if (q < G) f[q] = ld(F + (size_t)q * M + k);
+    for (uint32_t m = 0; m < G; ++m) {
+        fr_t acc = f_zero<FrP>();
+#pragma unroll
+        for (uint32_t q = 0; q < SHARD_MAX_RANKS; ++q)
+            if (q < G) acc = fr_add(acc, fr_mul(ld(coef + m * G + q), f[q]));
+        st(t + (size_t)m * M + k, acc);
+    }
 }
 
 // plonk_quotient_3wire_dev: coset NTTs of the wire polynomials, fused evaluation, coset iNTT.
@@ -236,7 +308,89 @@ struct ProverWorkspace {
     DevBuf<fr_t> totals, partial;
     DevBuf<uint32_t> flag;
     DevBuf<uint64_t> xchg;   // sharded proving: (lo, count) of every rank's SRS slice
+    // round 3 sharded by evaluation point (see fold_kernel): this rank's residue class of the 4n coset
+    DevBuf<fr_t> sl;         // [6][M] a b c z, z on the class of i + 4, pi: folded coefficients, then evaluations
+    DevBuf<fr_t> tq;         // [M]    t on the class, then F_q
+    DevBuf<fr_t> fall;       // [G][M] the F_q of all ranks
+    DevBuf<fr_t> ext_slice;  // [9][M] the key's coset tables on the class
+    DevBuf<fr_t> coef;       // [G][G] inverse DFT across the ranks, scaled
+    const Pk* slice_pk = nullptr;
+    uint32_t slice_g = 0, slice_q = 0;
 };
+
+// Geometry of a sharded round 3 for this rank.
+struct PointShard {
+    bool on = false;
+    uint32_t G = 1, log_g = 0, q = 0, q2 = 0, log_m = 0, zw_off = 4;
+    size_t M = 0;
+    fr_h s_q, c_q, s_q2, c_q2;   // class generators 7 w_4n^q and their M-th powers
+};
+
+static PointShard point_shard(const Pk* pk, const ShardInfo* shard) {
+    PointShard ps;
+    if (!shard || !shard->ex) return ps;
+    const uint32_t G = shard->ex->world;
+    const size_t n4 = 4 * pk->n;
+    if (G < 2 || G > SHARD_MAX_RANKS || (G & (G - 1)) || n4 / G < 16) return ps;   // otherwise round 3 stays replicated
+    ps.on = true;
+    ps.G = G;
+    while ((1u << ps.log_g) < G) ++ps.log_g;
+    ps.q = shard->ex->rank;
+    ps.M = n4 / G;
+    ps.log_m = pk->log_n + 2 - ps.log_g;
+    ps.q2 = (ps.q + 4) % G;
+    ps.zw_off = (ps.q + 4) >> ps.log_g;
+    const fr_h w4 = host::fr_root_of_unity(pk->log_n + 2), g = Fr::from_u64(7);
+    ps.s_q = Fr::mul(g, Fr::pow_u64(w4, ps.q));
+    ps.c_q = Fr::pow_u64(ps.s_q, ps.M);
+    ps.s_q2 = Fr::mul(g, Fr::pow_u64(w4, ps.q2));
+    ps.c_q2 = Fr::pow_u64(ps.s_q2, ps.M);
+    return ps;
+}
+
+// Per (key, world, rank): the key's coset tables on this rank's class and the recombination matrix.
+static void point_shard_tables(Ctx* ctx, ProverWorkspace* ws, const Pk* pk, const PointShard& ps) {
+    const size_t M = ps.M, n4 = 4 * pk->n;
+    ws->sl.ensure(6 * M);
+    ws->tq.ensure(M);
+    ws->fall.ensure(n4);
+    if (ws->slice_pk == pk && ws->slice_g == ps.G && ws->slice_q == ps.q && ws->ext_slice.n >= 9 * M) return;
+    ws->ext_slice.ensure(9 * M);
+    hipLaunchKernelGGL(class_gather_kernel, dim3((uint32_t)((M + 255) / 256), 9), dim3(256), 0, ctx->stream, pk->ext.p, n4,
+                       ps.log_g, ps.q, (uint32_t)M, ws->ext_slice.p);
+    HIP_CHECK(hipGetLastError());
+    // coef[m][q'] = 7^(-M m) / G * w_G^(-q' m), w_G = w_4n^M
+    const fr_h w4 = host::fr_root_of_unity(pk->log_n + 2);
+    const fr_h wg_inv = Fr::inv(Fr::pow_u64(w4, M));
+    const fr_h gm_inv = Fr::inv(Fr::pow_u64(Fr::from_u64(7), M));
+    const fr_h g_inv = Fr::inv(Fr::from_u64(ps.G));
+    std::vector<fr_h> coef((size_t)ps.G * ps.G);
+    fr_h scale = g_inv;
+    for (uint32_t m = 0; m < ps.G; ++m) {
+        const fr_h step = Fr::pow_u64(wg_inv, m);
+        fr_h cur = scale;
+        for (uint32_t q = 0; q < ps.G; ++q) {
+            coef[(size_t)m * ps.G + q] = cur;
+            cur = Fr::mul(cur, step);
+        }
+        scale = Fr::mul(scale, gm_inv);
+    }
+    ws->coef.ensure(coef.size());
+    HIP_CHECK(hipMemcpyAsync(ws->coef.p, coef.data(), coef.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ws->slice_pk = pk;
+    ws->slice_g = ps.G;
+    ws->slice_q = ps.q;
+}
+
+// evaluations of the polynomial `coeffs` (len coefficients) on the class generated by s: fold, then one coset transform
+static void class_evaluate(Ctx* ctx, hipStream_t stream, const fr_t* coeffs, size_t len, const PointShard& ps, const fr_h& s,
+                           const fr_h& c, fr_t* out) {
+    hipLaunchKernelGGL(fold_kernel, dim3((uint32_t)((ps.M + 255) / 256)), dim3(256), 0, stream, coeffs, (uint32_t)len, (uint32_t)ps.M,
+                       to_dev(c), out);
+    HIP_CHECK(hipGetLastError());
+    ntt_run_shift_on(ctx, stream, out, ps.log_m, NTT_COSET, s, 1, 0);
+}
 
 static ProverWorkspace* prover_workspace(Ctx* ctx) {
     if (!ctx->prover_ws)
@@ -368,6 +522,12 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         shard_check_coverage(ctx, ws, srs, &shard_local);
         shard = &shard_local;
     }
+    const PointShard ps = point_shard(pk, shard);
+    fr_t* SL[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (ps.on) {
+        point_shard_tables(ctx, ws, pk, ps);
+        for (int k = 0; k < 6; ++k) SL[k] = ws->sl.p + k * ps.M;
+    }
     fr_h bl[11];
     for (int i = 0; i < 11; ++i) {
         memcpy(bl[i].l, blinding[i].l, 32);
@@ -402,7 +562,13 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     host::G1AffineH comm[9];
     // the wires' evaluations on the 4n coset (round 3 reads them; they depend on no challenge) are
     // computed while the last commitment's reduction drains
-    const MsmFiller coset_abc = [&](hipStream_t s) { ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4, n + 2); };
+    const MsmFiller coset_abc = [&](hipStream_t s) {
+        if (!ps.on) {
+            ntt_run_on(ctx, s, W[0], log_n + 2, NTT_COSET, 3, n4, n + 2);
+            return;
+        }
+        for (int k = 0; k < 3; ++k) class_evaluate(ctx, s, W[k], n + 2, ps, ps.s_q, ps.c_q, SL[k]);
+    };
     // wire by wire: the device transforms and commits one wire while the next is prepared -- for a
     // host witness the pageable upload keeps the host busy staging meanwhile
     MsmBatch r1;
@@ -447,8 +613,14 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_blind(ctx, W[3], (uint32_t)n, b3, 3);
         poly_copy(ctx, CO[3], W[3], n + 3);
     }
-    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard,
-                         [&](hipStream_t s) { ntt_run_on(ctx, s, W[3], log_n + 2, NTT_COSET, 1, 0, n + 3); });
+    comm[3] = commit_dev(ctx, srs, CO[3], n + 3, ws->flag.p, shard, [&](hipStream_t s) {
+        if (!ps.on) {
+            ntt_run_on(ctx, s, W[3], log_n + 2, NTT_COSET, 1, 0, n + 3);
+            return;
+        }
+        class_evaluate(ctx, s, W[3], n + 3, ps, ps.s_q, ps.c_q, SL[3]);
+        if (ps.q2 != ps.q) class_evaluate(ctx, s, W[3], n + 3, ps, ps.s_q2, ps.c_q2, SL[4]);   // z(w X): the class of i + 4
+    });
     check_flag(ctx, ws);
     tr.absorb_g1("z_comm", comm[3]);
     const fr_h alpha = tr.squeeze_challenge("alpha");
@@ -463,9 +635,25 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         ntt_run(ctx, W[4], log_n, NTT_INVERSE, 1, 0);
         has_pi = true;
     }
-    if (has_pi) ntt_run(ctx, W[4], log_n + 2, NTT_COSET, 1, 0, n);
-    quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
-    ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
+    if (!ps.on) {
+        if (has_pi) ntt_run(ctx, W[4], log_n + 2, NTT_COSET, 1, 0, n);
+        quotient_run(ctx, pk, W[0], W[1], W[2], W[3], has_pi ? W[4] : nullptr, alpha, beta, gamma, ws->t.p);
+        ntt_run(ctx, ws->t.p, log_n + 2, NTT_COSET | NTT_INVERSE, 1, 0);
+    } else {
+        if (has_pi) class_evaluate(ctx, st, W[4], n, ps, ps.s_q, ps.c_q, SL[5]);
+        QuotientSlice qs;
+        qs.log_g = ps.log_g;
+        qs.q = ps.q;
+        qs.ext = ws->ext_slice.p;
+        qs.zw = ps.q2 != ps.q ? SL[4] : nullptr;
+        qs.zw_off = ps.zw_off;
+        quotient_run(ctx, pk, SL[0], SL[1], SL[2], SL[3], has_pi ? SL[5] : nullptr, alpha, beta, gamma, ws->tq.p, qs);
+        ntt_run_shift(ctx, ws->tq.p, ps.log_m, NTT_COSET | NTT_INVERSE, ps.s_q, 1, 0);   // F_q = t mod (X^M - c_q)
+        shard->ex->allgather(ws->tq.p, ws->fall.p, ps.M * sizeof(fr_t), st);
+        hipLaunchKernelGGL(recombine_kernel, dim3((uint32_t)((ps.M + 255) / 256)), dim3(256), 0, st, ws->fall.p, ps.G, (uint32_t)ps.M,
+                           ws->coef.p, ws->t.p);
+        HIP_CHECK(hipGetLastError());
+    }
     poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
     poly_copy(ctx, TP[0], ws->t.p, n);
     poly_copy(ctx, TP[1], ws->t.p + n, n);

@@ -78,47 +78,74 @@ def test_sharded_commit_exchange_gloo(tmp_path):
 
 
 GPU_WORKER = r'''
-import hashlib, json, os, sys
+import hashlib, json, os, random, sys
 sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
 import torch.distributed as dist
 import plonk_amd as pa
 from plonk_amd import circuits, sharded
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-k = int(os.environ["PLONK_TEST_LOG_N"])
-circ = circuits.SyntheticCircuit(k)
-n = circ.n
-ctx = pa.Context(0)   # both ranks share the one GPU of the test box
+case = os.environ["PLONK_TEST_CASE"]
+ctx = pa.Context(0)   # all ranks share the one GPU of the test box
 comm = sharded.Communicator(ctx, dist, rank, world, kind="callback")
+pis = []
+if case.startswith("pi"):
+    # public-input gates feeding a mul/add chain: the PI polynomial takes part in the sharded round 3
+    from oracle import protocol as P, fft as offt
+    from test_gpu_parity import _public_input_circuit, _oracle_case
+    cs, pis = _public_input_circuit(int(case[2:]))
+    n = cs.n
+    rng = random.Random(7)
+    blinding = [rng.randrange(pa.api.R_MOD) for _ in range(11)]
+    tau = 0xC0FFEE1234567
+    _, _, _, perm, proof_o, _ = _oracle_case(cs, tau, blinding, pis)
+    want = P.proof_to_bytes(proof_o)
+    wires, selectors = cs.wire_values(), cs.selectors()
+    sigmas, k1, k2, positions = [perm.s_sigma1_evals, perm.s_sigma2_evals, perm.s_sigma3_evals], perm.k1, perm.k2, cs.public_input_positions
+else:
+    k = int(case)
+    circ = circuits.SyntheticCircuit(k)
+    n, tau, blinding = circ.n, circ.tau, circ.blinding
+    wires, selectors, sigmas, k1, k2, positions = circ.wires, circ.selectors, circ.sigmas, circ.k1, circ.k2, ()
+    es = [e for e in json.load(open(os.path.join(%(root)r, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^%%d" %% k]
+    want = bytes.fromhex(es[0]["proof"]) if es else None
 lo, hi = sharded.point_range(n + 11, rank, world)
-srs = pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
+srs = pa.Srs.from_tau_range(tau, lo, hi, ctx=ctx)
 assert len(srs) == hi - lo
-pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
-proof = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi)).prove([], circ.blinding)
+pk = pa.ProvingKey(n, selectors, sigmas, k1, k2, positions, ctx=ctx)
+prover = pa.Prover(wires, pk, srs, resident=True, comm=comm, shard=(lo, hi))
+proof = prover.prove(pis, blinding)
 calls, nbytes = comm.stats()
-assert calls == 1 + 9, calls   # the coverage check, then one all-gather per commitment MSM
+# the coverage check, one all-gather per commitment MSM, and -- when round 3 is sharded by evaluation
+# point (a power-of-two number of ranks) -- the slices of the quotient polynomial
+point_sharded = world & (world - 1) == 0
+assert calls == 1 + 9 + (1 if point_sharded else 0), calls
 assert comm.host.calls == calls
-if k == 16:
-    want = [e for e in json.load(open(os.path.join(%(root)r, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
-    assert proof.to_bytes().hex() == want["proof"], "sharded proof differs from the single-device golden proof"
+if point_sharded:
+    assert nbytes == 16 + 9 * (64 + 256 * 192) + (4 * n // world) * 32, nbytes
+if want is not None:
+    assert proof.to_bytes() == want, "sharded proof differs from the single-device proof"
 else:   # the digest test_prove_full_size_verifies pins for the single-device proof of this circuit
-    assert k == 20 and hashlib.sha256(proof.to_bytes()).hexdigest()[:16] == "8b3f972755329b78"
-# slices that do not tile the point range are refused on every rank (the single-device prover
-# returns PLONK_E_INVALID for a polynomial past the SRS; a gap would silently drop coefficients)
-bad = pa.Srs.from_tau_range(circ.tau, lo + (1 if rank else 0), hi, ctx=ctx)
-try:
-    pa.Prover(circ.wires, pk, bad, resident=True, comm=comm, shard=(lo + (1 if rank else 0), hi)).prove([], circ.blinding)
-    raise SystemExit("a gap in the point range was accepted")
-except pa.PlonkError as e:
-    assert e.code == pa._lib.PLONK_E_INVALID and "tile" in str(e), e
-# ... and so is an SRS whose ranks together hold fewer points than the blinded polynomials need
-lo2, hi2 = sharded.point_range(n + 1, rank, world)
-short = pa.Srs.from_tau_range(circ.tau, lo2, hi2, ctx=ctx)
-try:
-    pa.Prover(circ.wires, pk, short, resident=True, comm=comm, shard=(lo2, hi2)).prove([], circ.blinding)
-    raise SystemExit("a too-short sharded SRS was accepted")
-except pa.PlonkError as e:
-    assert e.code == pa._lib.PLONK_E_INVALID, e
+    assert case == "20" and hashlib.sha256(proof.to_bytes()).hexdigest()[:16] == "8b3f972755329b78"
+assert prover.prove(pis, blinding).to_bytes() == proof.to_bytes()   # and again on warm buffers
+if case == "16" and world == 2:
+    # slices that do not tile the point range are refused on every rank (the single-device prover
+    # returns PLONK_E_INVALID for a polynomial past the SRS; a gap would silently drop coefficients)
+    bad = pa.Srs.from_tau_range(tau, lo + (1 if rank else 0), hi, ctx=ctx)
+    try:
+        pa.Prover(wires, pk, bad, resident=True, comm=comm, shard=(lo + (1 if rank else 0), hi)).prove([], blinding)
+        raise SystemExit("a gap in the point range was accepted")
+    except pa.PlonkError as e:
+        assert e.code == pa._lib.PLONK_E_INVALID and "tile" in str(e), e
+    # ... and so is an SRS whose ranks together hold fewer points than the blinded polynomials need
+    lo2, hi2 = sharded.point_range(n + 1, rank, world)
+    short = pa.Srs.from_tau_range(tau, lo2, hi2, ctx=ctx)
+    try:
+        pa.Prover(wires, pk, short, resident=True, comm=comm, shard=(lo2, hi2)).prove([], blinding)
+        raise SystemExit("a too-short sharded SRS was accepted")
+    except pa.PlonkError as e:
+        assert e.code == pa._lib.PLONK_E_INVALID, e
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -129,30 +156,34 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [16, 20])
-def test_sharded_prove_two_ranks_one_gpu(tmp_path, k):
-    """plonk_prove_3wire_sharded with world_size 2 (gloo for the exchange, both ranks on cuda:0):
-    every rank's SRS slice gets its own window table, the ranks' shares of every MSM are all-gathered
-    (staged through the C callback), and both ranks emit the single-device proof: the golden 2^16
-    bytes, the pinned digest of the 2^20-gate benchmark configuration."""
+@pytest.mark.parametrize("world,case", [(2, "16"), (2, "20"), (4, "10"), (8, "14"), (3, "10"), (2, "pi9"), (8, "pi6")])
+def test_sharded_prove_ranks_on_one_gpu(tmp_path, world, case):
+    """plonk_prove_3wire_sharded with several ranks on cuda:0 (gloo + the callback communicator for the
+    exchange): every rank holds an SRS slice with its own window table; the ranks' shares of every MSM
+    are all-gathered; with a power-of-two number of ranks round 3 is sharded by evaluation point
+    (transforms of size 4n / world on the rank's residue class of the coset, quotient slices
+    all-gathered and recombined -- with 8 ranks z(wX) lives on another rank's class).  All ranks emit
+    the single-device proof: golden bytes (2^10 / 2^14 / 2^16), the pinned digest of the 2^20-gate
+    configuration, the oracle's bytes for circuits with public inputs."""
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER % {"root": ROOT})
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29537 + k),
-                   PLONK_TEST_LOG_N=str(k))
+    port = 29600 + world * 16 + sum(map(ord, case)) % 16
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PLONK_TEST_CASE=case)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=240)
+            out, _ = p.communicate(timeout=280)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             raise
         outs.append(out.decode())
     for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, out
+        assert p.returncode == 0, out[-3000:]
         assert "rank %d ok" % rank in out
 
 
@@ -174,7 +205,7 @@ def test_rccl_communicator_single_rank(ctx):
     want = [e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
     assert proof.to_bytes().hex() == want["proof"]
     calls, nbytes = comm.stats()
-    assert calls == 10 and nbytes == 16 + 9 * (64 + 256 * 192)
+    assert calls == 10 and nbytes == 16 + 9 * (64 + 256 * 192)   # one rank: round 3 is not sharded
     comm.close()
 
 
