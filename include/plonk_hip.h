@@ -188,6 +188,11 @@ int32_t plonk_comm_create_rccl(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BY
                                plonk_comm** out);
 int32_t plonk_comm_create_callback(plonk_ctx* ctx, uint32_t rank, uint32_t world, plonk_allgather_fn allgather,
                                    void* user, plonk_comm** out);
+/* Measurement aid: one rank of a `world`-rank proof running alone on its GPU.  Its all-gathers return
+ * copies of the rank's own record in every slot (device-to-device), and the balanced split of
+ * `total_points` (the first total_points % world ranks one point more) for the coverage check: the
+ * proof is NOT valid, the rank's device work is what it would be among real peers. */
+int32_t plonk_comm_create_loopback(plonk_ctx* ctx, uint32_t rank, uint32_t world, size_t total_points, plonk_comm** out);
 void plonk_comm_destroy(plonk_comm* comm);
 /* All-gathers issued through this handle and the bytes this rank contributed to them. */
 int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* bytes);

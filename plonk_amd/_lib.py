@@ -102,6 +102,7 @@ SIGNATURES = {
     "plonk_comm_unique_id": (_i32, [_vp]),
     "plonk_comm_create_rccl": (_i32, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
     "plonk_comm_create_callback": (_i32, [_vp, _u32, _u32, _vp, _vp, C.POINTER(_vp)]),
+    "plonk_comm_create_loopback": (_i32, [_vp, _u32, _u32, _sz, C.POINTER(_vp)]),
     "plonk_comm_destroy": (None, [_vp]),
     "plonk_comm_stats": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -411,6 +411,16 @@ int32_t plonk_comm_create_callback(plonk_ctx* ctx, uint32_t rank, uint32_t world
     API_END()
 }
 
+int32_t plonk_comm_create_loopback(plonk_ctx* ctx, uint32_t rank, uint32_t world, size_t total_points, plonk_comm** out) {
+    if (!ctx || !out) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    *out = nullptr;
+    std::unique_ptr<plonk_comm> c(new plonk_comm());
+    c->ex.reset(comm_create_loopback(C_->device, rank, world, total_points));
+    *out = c.release();
+    API_END()
+}
+
 void plonk_comm_destroy(plonk_comm* comm) { delete comm; }
 
 int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* bytes) {

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -89,7 +90,44 @@ struct CallbackExchange : Exchange {
     const char* kind() const override { return "callback"; }
 };
 
+// Measurement aid: rank `rank` of a `world`-rank proof running alone.  Every rank's slot of an all-gather is
+// filled with this rank's own record by device-to-device copies, except the 16-byte (first point, count)
+// records of the coverage check, which are made up as the balanced split of `total_points`.  The proofs that
+// come out are not valid; the device work of the rank (its shares of the MSMs, its class of round 3) is real.
+struct LoopbackExchange : Exchange {
+    size_t total_points = 0;
+    void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
+        if (nbytes == 2 * sizeof(uint64_t)) {
+            std::vector<uint64_t> rec(2 * (size_t)world);
+            const size_t base = total_points / world, extra = total_points % world;
+            for (uint32_t r = 0; r < world; ++r) {
+                rec[2 * r] = r * base + std::min<size_t>(r, extra);
+                rec[2 * r + 1] = base + (r < extra ? 1 : 0);
+            }
+            HIP_CHECK(hipMemcpyAsync(recv_dev, rec.data(), rec.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        } else {
+            for (uint32_t r = 0; r < world; ++r)
+                HIP_CHECK(hipMemcpyAsync(static_cast<char*>(recv_dev) + (size_t)r * nbytes, send_dev, nbytes,
+                                         hipMemcpyDeviceToDevice, stream));
+        }
+        ++calls;
+        bytes += nbytes;
+    }
+    const char* kind() const override { return "loopback"; }
+};
+
 }  // namespace
+
+Exchange* comm_create_loopback(int device, uint32_t rank, uint32_t world, size_t total_points) {
+    PLONK_REQUIRE(world >= 1 && rank < world, "comm: rank must be below world");
+    std::unique_ptr<LoopbackExchange> ex(new LoopbackExchange());
+    ex->rank = rank;
+    ex->world = world;
+    ex->device = device;
+    ex->total_points = total_points;
+    return ex.release();
+}
 
 void comm_unique_id(uint8_t out[COMM_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) == COMM_ID_BYTES, "ncclUniqueId size");

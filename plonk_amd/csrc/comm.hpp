@@ -27,6 +27,7 @@ struct Exchange {
 constexpr size_t COMM_ID_BYTES = 128;   // ncclUniqueId
 void comm_unique_id(uint8_t out[COMM_ID_BYTES]);
 Exchange* comm_create_rccl(int device, const uint8_t id[COMM_ID_BYTES], uint32_t rank, uint32_t world);
+Exchange* comm_create_loopback(int device, uint32_t rank, uint32_t world, size_t total_points);
 Exchange* comm_create_callback(int device, uint32_t rank, uint32_t world, plonk_allgather_fn fn, void* user);
 
 }  // namespace plonk

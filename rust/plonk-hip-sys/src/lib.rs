@@ -174,6 +174,8 @@ extern "C" {
     pub fn plonk_comm_create_rccl(ctx: *mut PlonkCtx, id: *const u8, rank: u32, world: u32, out: *mut *mut PlonkComm) -> i32;
     pub fn plonk_comm_create_callback(ctx: *mut PlonkCtx, rank: u32, world: u32, allgather: PlonkAllgatherFn,
                                       user: *mut c_void, out: *mut *mut PlonkComm) -> i32;
+    pub fn plonk_comm_create_loopback(ctx: *mut PlonkCtx, rank: u32, world: u32, total_points: usize,
+                                      out: *mut *mut PlonkComm) -> i32;
     pub fn plonk_comm_destroy(comm: *mut PlonkComm);
     pub fn plonk_comm_stats(comm: *const PlonkComm, calls: *mut u64, bytes: *mut u64) -> i32;
     pub fn plonk_prove_3wire_sharded(ctx: *mut PlonkCtx, pk: *const PlonkPk, srs_slice: *const PlonkSrs, shard_lo: usize,
