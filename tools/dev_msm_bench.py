@@ -5,6 +5,8 @@ import time
 
 import numpy as np
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plonk_amd as pa
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
