@@ -301,11 +301,12 @@ struct ProverWorkspace {
     DevBuf<fr_t> t;       // [4n]
     DevBuf<fr_t> ev;      // [3][n]   wire evaluations
     DevBuf<fr_t> co;      // [4][n+8] blinded coefficient vectors a b c z
-    DevBuf<fr_t> num, den, scr;  // [n]
+    DevBuf<fr_t> scr;     // [n]
     DevBuf<fr_t> tp;      // [3][n+8] t_lo t_mid t_hi (blinded)
     DevBuf<fr_t> wnum, wq, wq2, tmp;  // [n+8]
     DevBuf<fr_t> evals;   // [8]
     DevBuf<fr_t> totals, partial;
+    DevBuf<fr_t> powtab;  // power tables of zeta, 1/zeta, zeta omega, 1/(zeta omega) for rounds 4-5
     DevBuf<uint32_t> flag;
     DevBuf<uint64_t> xchg;   // sharded proving: (lo, count) of every rank's SRS slice
     // round 3 sharded by evaluation point (see fold_kernel): this rank's residue class of the 4n coset
@@ -511,7 +512,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     const uint32_t log_n = pk->log_n;
     ProverWorkspace* ws = prover_workspace(ctx);
     ws->w4.ensure(5 * n4); ws->t.ensure(n4); ws->ev.ensure(3 * n); ws->co.ensure(4 * ns);
-    ws->num.ensure(n); ws->den.ensure(n); ws->scr.ensure(n); ws->tp.ensure(3 * ns);
+    ws->scr.ensure(n); ws->tp.ensure(3 * ns);
     ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->wq2.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
     hipStream_t st = ctx->stream;
     ShardInfo shard_local;
@@ -599,13 +600,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         p.a = EV[0]; p.b = EV[1]; p.c = EV[2];
         p.s1 = pk->sig_ev.p; p.s2 = pk->sig_ev.p + n; p.s3 = pk->sig_ev.p + 2 * n;
         p.w_lo = pk->w_lo.p; p.w_hi = pk->w_hi.p;
-        p.num = ws->num.p; p.den = ws->den.p;
         p.beta = to_dev(beta); p.gamma = to_dev(gamma); p.k1 = to_dev(pk->k1); p.k2 = to_dev(pk->k2);
+        p.omega = to_dev(pk->omega);
         p.n = (uint32_t)n; p.log_l = pk->log_lw;
-        perm_terms(ctx, p);
         // only i < n-1 enter the product (:271); the last ratio is never read by the exclusive scan
-        perm_ratio(ctx, ws->num.p, ws->den.p, (uint32_t)n - 1, ws->scr.p, ws->flag.p);
-        scan_prefix_product(ctx, ws->den.p, W[3], (uint32_t)n, ws->totals);
+        perm_grand_product(ctx, p, W[3], ws->scr.p, ws->flag.p, ws->totals);
     }
     ntt_run(ctx, W[3], log_n, NTT_INVERSE, 1, 0);
     {
@@ -679,8 +678,14 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     // subtracted from the constant term changes the remainder, not the quotient -- so its commitment
     // is started here and runs underneath rounds 4 and 5; it enters the proof in the reference's order.
     MsmBatch openings;
+    const fr_h zeta_inv = Fr::inv(zeta), zeta_omega_inv = Fr::inv(zeta_omega);
+    PowTab tabs[4];   // zeta, 1/zeta, zeta omega, 1/(zeta omega)
+    {
+        const fr_h pts[4] = {zeta, zeta_inv, zeta_omega, zeta_omega_inv};
+        pow_tables(ctx, pts, 4, (uint32_t)n + 8, ws->powtab, tabs);
+    }
     HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
-    poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, ws->tmp.p, ws->wq2.p, ws->totals);
+    poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->tmp.p, ws->wq2.p, ws->totals);
     commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard);
     fr_h e6[6];
     {
@@ -691,7 +696,8 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         for (int k = 0; k < 6; ++k) {
             ea.coeffs[k] = polys[k];
             ea.len[k] = lens[k];
-            ea.x[k] = to_dev(k == 5 ? zeta_omega : zeta);
+            ea.lo[k] = tabs[k == 5 ? 2 : 0].lo;
+            ea.hi[k] = tabs[k == 5 ? 2 : 0].hi;
         }
         poly_eval_batch(ctx, ea, 6, ws->evals.p, ws->partial);
         HIP_CHECK(hipMemcpyAsync(e6, ws->evals.p, 6 * sizeof(fr_t), hipMemcpyDeviceToHost, st));
@@ -727,7 +733,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         memset(&la, 0, sizeof(la));
         uint32_t k = 0;
         auto term = [&](const fr_t* p, size_t len, const fr_h& s) {
-            la.p[k] = p; la.len[k] = (uint32_t)len; la.s[k] = to_dev(s); ++k;
+            la.p[k] = p; la.len[k] = (uint32_t)len; la.s[k] = lincomb_scalar(s); ++k;
         };
         term(pk->coef.p + 0 * n, n, Fr::mul(a_bar, b_bar));  // q_M  (:742)
         term(pk->coef.p + 1 * n, n, a_bar);                  // q_L
@@ -750,14 +756,14 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         // subtract the value at zeta (= r(zeta) + v a_bar + ... + v^5 s2_bar) from the constant term
         EvalArgs ea;
         memset(&ea, 0, sizeof(ea));
-        ea.coeffs[0] = ws->wnum.p; ea.len[0] = wlen; ea.x[0] = to_dev(zeta);
+        ea.coeffs[0] = ws->wnum.p; ea.len[0] = wlen; ea.lo[0] = tabs[0].lo; ea.hi[0] = tabs[0].hi;
         poly_eval_batch(ctx, ea, 1, ws->evals.p + 6, ws->partial);
         fr_h at_zeta;
         HIP_CHECK(hipMemcpyAsync(&at_zeta, ws->evals.p + 6, sizeof(fr_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
-        poly_div_linear(ctx, ws->wnum.p, wlen, zeta, ws->tmp.p, ws->wq.p, ws->totals);                   // :809
+        poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
         commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard);
         host::G1AffineH w[2];
         commit_finish(ctx, openings, shard, w);
