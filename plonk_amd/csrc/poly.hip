@@ -12,115 +12,6 @@
 
 namespace plonk {
 
-__device__ __forceinline__ fr_t fr_pow_u64(fr_t b, uint64_t e) {
-    fr_t r = f_one<FrP>();
-    while (e) {
-        if (e & 1ull) r = fr_mul(r, b);
-        b = fr_mul(b, b);
-        e >>= 1;
-    }
-    return r;
-}
-
-// ---- inversion of a nonzero Montgomery residue by the binary "almost inverse" (Kaliski): the loop
-//      below ends with r = -a^-1 2^k mod p, 255 <= k <= 510, after k rounds of shifts, one 256-bit
-//      subtraction and one addition each -- about a fifth of the dependent instructions of the
-//      exponentiation a^(p-2), which matters because one lane's inversion is the longest chain of
-//      the round-2 kernel.  With a = x R the wanted x^-1 R is (p - r) * 2^(512 - k). ----
-struct U256 {
-    uint32_t l[8];
-};
-__device__ __forceinline__ U256 u256_shr1(const U256& a) {
-    U256 r;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) r.l[i] = (a.l[i] >> 1) | (a.l[i + 1] << 31);
-    r.l[7] = a.l[7] >> 1;
-    return r;
-}
-__device__ __forceinline__ U256 u256_shl1(const U256& a) {
-    U256 r;
-    r.l[0] = a.l[0] << 1;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) r.l[i] = (a.l[i] << 1) | (a.l[i - 1] >> 31);
-    return r;
-}
-__device__ __forceinline__ U256 u256_add(const U256& a, const U256& b) {
-    U256 r;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t)a.l[i] + b.l[i];
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    return r;
-}
-// a - b and whether it borrowed (a < b)
-__device__ __forceinline__ U256 u256_sub(const U256& a, const U256& b, bool& borrow) {
-    U256 r;
-    int64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (int64_t)a.l[i] - (int64_t)b.l[i];
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    borrow = c != 0;
-    return r;
-}
-__device__ __forceinline__ U256 u256_sel(bool take_a, const U256& a, const U256& b) {
-    U256 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = take_a ? a.l[i] : b.l[i];
-    return r;
-}
-
-__device__ __noinline__ fr_t fr_inverse(const fr_t& a) {
-    U256 u, v, r, s, pm;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        pm.l[i] = FrP::p(i);
-        u.l[i] = pm.l[i];
-        v.l[i] = a.l[i];
-        r.l[i] = 0;
-        s.l[i] = i == 0 ? 1u : 0u;
-    }
-    uint32_t k = 0;
-#pragma unroll 1
-    for (;;) {
-        uint32_t any = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) any |= v.l[i];
-        if (any == 0 || k >= 512u) break;   // k <= 510 for any nonzero residue below p; the cap bounds the loop on other input
-        const bool u_even = (u.l[0] & 1u) == 0, v_even = (v.l[0] & 1u) == 0;
-        bool u_lt_v, v_lt_u;
-        const U256 umv = u256_sub(u, v, u_lt_v);
-        const U256 vmu = u256_sub(v, u, v_lt_u);
-        const bool case_a = u_even, case_b = !u_even && v_even;
-        const bool case_c = !u_even && !v_even && v_lt_u;    // u > v
-        const bool case_d = !u_even && !v_even && !v_lt_u;   // u <= v (equal only at u = v = 1: v becomes 0)
-        const U256 t = u256_add(r, s);
-        u = case_a ? u256_shr1(u) : (case_c ? u256_shr1(umv) : u);
-        v = case_b ? u256_shr1(v) : (case_d ? u256_shr1(vmu) : v);
-        if (case_c) r = t;
-        if (case_d) s = t;
-        if (case_a || case_c) s = u256_shl1(s);
-        else r = u256_shl1(r);
-        ++k;
-    }
-    bool lt;
-    const U256 r_red = u256_sub(r, pm, lt);
-    r = u256_sel(lt, r, r_red);                 // r mod p
-    const U256 res = u256_sub(pm, r, lt);       // p - r = a^-1 2^k mod p
-    // times 2^(512 - k): as a Montgomery product with the Montgomery form of that power of two
-    fr_t pow2 = f_one<FrP>(), out;
-#pragma unroll 1
-    for (uint32_t i = 0; i < 512u - k; ++i) pow2 = fr_add(pow2, pow2);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out.l[i] = res.l[i];
-    return fr_mul(out, pow2);
-}
-
 // coeffs[j] -= bl[j], coeffs[n + j] += bl[j], j < k:  adds (bl[k-1] X^(k-1) + ... + bl[0]) * (X^n - 1)
 __global__ void blind_kernel(fr_t* coeffs, uint32_t n, BlindArgs b) {
     const uint32_t j = threadIdx.x;
@@ -144,33 +35,46 @@ __global__ void poke_kernel(fr_t* coeffs, uint32_t idx, fr_t v, int subtract) {
 //      Slot of element u: one pad element per chunk, so the lanes' chunks start 9 elements apart. ----
 static constexpr uint32_t PT = 256, PE = 8, PW = PT * PE;
 static constexpr uint32_t STAGE_ELEMS = PT * (PE + 1);
-__device__ __forceinline__ uint32_t stage_slot(uint32_t u) { return u + u / PE; }
+// the same with E elements a lane (a workgroup then covers 256 E): E + 1 slots a lane
+template <uint32_t E>
+__device__ __forceinline__ uint32_t stage_slot(uint32_t u) { return u + u / E; }
 
-// v[j] = g[index(base + 8 t + j)] for logical indices below len, `fill` above; index(r) = r, or len - 1 - r (reverse)
-__device__ __forceinline__ void stage_in(const fr_t* __restrict__ g, uint32_t base, uint32_t len, bool reverse, fr_t* stage,
-                                         fr_t (&v)[PE], const fr_t& fill) {
+// global -> LDS half of stage_in: stage[slot(u)] = g[index(base + u)] for logical indices below len, `fill` above;
+// index(r) = r, or len - 1 - r (reverse)
+template <uint32_t E>
+__device__ __forceinline__ void stage_load(const fr_t* __restrict__ g, uint32_t base, uint32_t len, bool reverse, fr_t* stage,
+                                           const fr_t& fill) {
     const uint32_t t = threadIdx.x;
-#pragma unroll
-    for (uint32_t m = 0; m < PE; ++m) {
+#pragma clang loop unroll(full)
+    for (uint32_t m = 0; m < E; ++m) {
         const uint32_t u = t + m * PT, r = base + u;
-        st(&stage[stage_slot(u)], r < len ? ld(g + (reverse ? len - 1 - r : r)) : fill);
+        st(&stage[stage_slot<E>(u)], r < len ? ld(g + (reverse ? len - 1 - r : r)) : fill);
     }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) v[j] = ld(&stage[stage_slot(t * PE + j)]);
     __syncthreads();
 }
 
-__device__ __forceinline__ void stage_out(fr_t* __restrict__ g, uint32_t base, uint32_t len, bool reverse, fr_t* stage,
-                                          const fr_t (&v)[PE]) {
+// v[j] = g[index(base + E t + j)]
+template <uint32_t E>
+__device__ __forceinline__ void stage_in(const fr_t* __restrict__ g, uint32_t base, uint32_t len, bool reverse, fr_t* stage,
+                                         fr_t (&v)[E], const fr_t& fill) {
     const uint32_t t = threadIdx.x;
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) st(&stage[stage_slot(t * PE + j)], v[j]);
+    stage_load<E>(g, base, len, reverse, stage, fill);
+#pragma clang loop unroll(full)
+    for (uint32_t j = 0; j < E; ++j) v[j] = ld(&stage[stage_slot<E>(t * E + j)]);
     __syncthreads();
-#pragma unroll
-    for (uint32_t m = 0; m < PE; ++m) {
+}
+
+template <uint32_t E>
+__device__ __forceinline__ void stage_out(fr_t* __restrict__ g, uint32_t base, uint32_t len, bool reverse, fr_t* stage,
+                                          const fr_t (&v)[E]) {
+    const uint32_t t = threadIdx.x;
+#pragma clang loop unroll(full)
+    for (uint32_t j = 0; j < E; ++j) st(&stage[stage_slot<E>(t * E + j)], v[j]);
+    __syncthreads();
+#pragma clang loop unroll(full)
+    for (uint32_t m = 0; m < E; ++m) {
         const uint32_t u = t + m * PT, r = base + u;
-        if (r < len) st(g + (reverse ? len - 1 - r : r), ld(&stage[stage_slot(u)]));
+        if (r < len) st(g + (reverse ? len - 1 - r : r), ld(&stage[stage_slot<E>(u)]));
     }
     __syncthreads();
 }
@@ -223,125 +127,245 @@ __global__ __launch_bounds__(256) void pow_table_kernel(PowTabArgs a) {
     st(a.out + (size_t)which * per + e, r);
 }
 
-// ---- round 2 (prover.rs:265-302) in one pass per workgroup of 2048 gates: the factors num_i, den_i, the ratios
-//      num_i / den_i by Montgomery's trick over the whole workgroup (ONE inversion per 2048 denominators, by the
-//      binary almost-inverse above), and the exclusive prefix products of the ratios inside the workgroup.
-//      local[i] = prod of the ratios before i in its workgroup; totals[wg] = prod of the workgroup's ratios.
-//      A zero denominator sets *flag (prover.rs:290 panics "Denominator is zero"). ----
-__global__ __launch_bounds__(256) void perm_fused_kernel(PermArgs p, fr_t* __restrict__ local, fr_t* __restrict__ totals,
-                                                         uint32_t* __restrict__ flag) {
+// ---- round 2 (prover.rs:265-302): z_i = prod_{j<i} num_j / den_j without per-element division state.
+//      With N(<i) the product of the numerators before i, D(>=i) the product of the denominators from i on:
+//          z_i = N(<i) D(>=i) / D(all).
+//      perm_tile_kernel, one workgroup per tile of 1024 gates: local[i] = N(<i) D(>=i) restricted to the tile, and the
+//      tile's two products.  perm_middle_kernel, one workgroup: offs[w] = (numerators of the tiles before w)
+//      (denominators of the tiles after w), and the product of all denominators, whose inverse -- the only inversion --
+//      is taken on the host (a single lane of the device needs 0.2 ms for it, the round trip 0.05 ms).
+//      z_i = offs[tile] local[i] / D(all).
+//      A zero denominator sets *flag (prover.rs:290 panics "Denominator is zero").
+//      The tile kernel computes in the 29-bit-limb form.  Stored vectors regrouped into 29-bit limbs read as
+//      value / 32 ("scaled"); constants come as true values of the form.  scaled x true = scaled; scaled x scaled
+//      loses a factor 32.  Each of num_j, den_j is a product of three scaled factors, i.e. the true-form image of
+//      the value times 2^-15; every z_i holds as many numerators as denominators, so these factors cancel. ----
+static constexpr uint32_t QE = 4, QW = PT * QE, QW_LOG = 10;   // gates a lane, gates a tile
+static constexpr uint32_t Q_STAGE = PT * (QE + 1);
+
+__device__ __forceinline__ frx ld_slot(const frx_slot* p) { return ld_tw(p); }
+__device__ __forceinline__ void st_slot(frx_slot* p, const frx& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
+}
+__device__ __forceinline__ frx frx_from(const PermScalar& c) {
+    frx r;
+#pragma clang loop unroll(full)
+    for (int w = 0; w < 9; ++w) r.l[w] = c.w[w];
+    return r;
+}
+// the value of the lane `delta` below (up) or above (down) in the wavefront
+__device__ __forceinline__ frx x_shfl(const frx& v, uint32_t delta, bool up) {
+    frx r;
+#pragma clang loop unroll(full)
+    for (int w = 0; w < 9; ++w) r.l[w] = up ? __shfl_up(v.l[w], delta, 64) : __shfl_down(v.l[w], delta, 64);
+    return r;
+}
+
+// Lane totals of a workgroup -> for every lane the product of the lanes before it (forward) or after it (backward),
+// done by ONE wavefront: its lane l owns the four totals 4 l .. 4 l + 3, multiplies through them, the 64 chunk
+// products are scanned with wavefront shuffles, and the chunk's offset is multiplied back in.
+// slots: 256 + 64 entries, entry u at u + u / 4; on return slots[..] hold the exclusive products, *total everything.
+__device__ __forceinline__ uint32_t lane_slot(uint32_t u) { return u + (u >> 2); }
+__device__ __forceinline__ void wave_scan_totals(frx_slot* slots, bool forward, frx_slot* total) {
+    const uint32_t l = threadIdx.x & 63u;
+    frx run = x_one<FrX>();
+#pragma clang loop unroll(full)
+    for (uint32_t kk = 0; kk < 4; ++kk) {
+        const uint32_t u = 4 * l + (forward ? kk : 3 - kk);
+        const frx v = ld_slot(&slots[lane_slot(u)]);
+        st_slot(&slots[lane_slot(u)], run);
+        run = x_mul<FrX>(run, v);
+    }
+    frx incl = run;
+#pragma clang loop unroll(full)
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const frx o = x_shfl(incl, off, forward);
+        const bool has = forward ? l >= off : l + off < 64;
+        const frx m = x_mul<FrX>(o, incl);
+        if (has) incl = m;
+    }
+    frx excl = x_shfl(incl, 1, forward);
+    if (forward ? l == 0 : l == 63) excl = x_one<FrX>();
+    if (forward ? l == 63 : l == 0) st_slot(total, incl);
+#pragma clang loop unroll(full)
+    for (uint32_t kk = 0; kk < 4; ++kk) {
+        const uint32_t u = 4 * l + kk;
+        st_slot(&slots[lane_slot(u)], x_mul<FrX>(ld_slot(&slots[lane_slot(u)]), excl));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void perm_tile_kernel(PermArgs p, fr_t* __restrict__ local, fr_t* __restrict__ tot_n,
+                                                        fr_t* __restrict__ tot_d, uint32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char perm_lds[];
     fr_t* stage = reinterpret_cast<fr_t*>(perm_lds);
-    fr_t* part = stage + STAGE_ELEMS;
-    fr_t* part2 = part + PT;
-    const uint32_t t = threadIdx.x, base = blockIdx.x * PW, i0 = base + t * PE;
-    const fr_t zero = f_zero<FrP>(), one = f_one<FrP>();
-    fr_t num[PE], den[PE];
+    // after the inputs are in registers the staging area holds the lane totals
+    frx_slot* slots_n = reinterpret_cast<frx_slot*>(perm_lds);
+    frx_slot* slots_d = slots_n + 320;
+    frx_slot* tile_tot = slots_d + 320;   // [0] numerators, [1] denominators
+    const uint32_t t = threadIdx.x, base = blockIdx.x * QW, i0 = base + t * QE;
+    const fr_t zero = f_zero<FrP>();
+    const frx one = x_one<FrX>();
+    const frx beta = frx_from(p.beta_x), gamma = x_repack_in<FrX>(p.gamma), omega = frx_from(p.omega_x);   // true; scaled; true
+    // beta w^i0, scaled: (32 beta) w_lo w_hi, or beta w_lo where there is no high factor
+    frx bw0 = one;
+    if (i0 < p.n) {
+        const frx wl = x_repack_in<FrX>(ld(p.w_lo + (i0 & ((1u << p.log_l) - 1u))));
+        if (i0 >> p.log_l)
+            bw0 = x_mul<FrX>(x_mul<FrX>(wl, frx_from(p.beta32_x)), x_repack_in<FrX>(ld(p.w_hi + (i0 >> p.log_l))));
+        else
+            bw0 = x_mul<FrX>(wl, beta);
+    }
+    frx num[QE], den[QE];
+    fr_t w[QE];
+    // wire a against the identity beta w^i and S_sigma1
+    stage_in<QE>(p.a, base, p.n, false, stage, w, zero);
+    stage_load<QE>(p.s1, base, p.n, false, stage, zero);
     {
-        fr_t a[PE], s[PE];
-        fr_t w = one;
-        if (i0 < p.n) {
-            w = ld(p.w_lo + (i0 & ((1u << p.log_l) - 1u)));
-            if (i0 >> p.log_l) w = fr_mul(w, ld(p.w_hi + (i0 >> p.log_l)));
+        frx id = bw0;
+#pragma clang loop unroll(full)
+        for (uint32_t j = 0; j < QE; ++j) {
+            const frx wg = x_add_lazy<FrX>(x_repack_in<FrX>(w[j]), gamma);
+            const frx sg = x_repack_in<FrX>(ld(&stage[stage_slot<QE>(t * QE + j)]));
+            num[j] = x_norm_u<FrX>(x_add_lazy<FrX>(wg, id));                          // below 4p
+            den[j] = x_norm_u<FrX>(x_add_lazy<FrX>(wg, x_mul<FrX>(sg, beta)));
+            if (j + 1 < QE) id = x_mul<FrX>(id, omega);
         }
-        fr_t bw[PE];
-#pragma unroll
-        for (uint32_t j = 0; j < PE; ++j) {
-            bw[j] = fr_mul(p.beta, w);
-            w = fr_mul(w, p.omega);
+    }
+    __syncthreads();
+    // wires b and c against k1 beta w^i, S_sigma2 and k2 beta w^i, S_sigma3
+#pragma unroll 1
+    for (uint32_t k = 1; k < 3; ++k) {
+        stage_in<QE>(k == 1 ? p.b : p.c, base, p.n, false, stage, w, zero);
+        stage_load<QE>(k == 1 ? p.s2 : p.s3, base, p.n, false, stage, zero);
+        frx id = x_mul<FrX>(bw0, frx_from(k == 1 ? p.k1_x : p.k2_x));
+#pragma clang loop unroll(full)
+        for (uint32_t j = 0; j < QE; ++j) {
+            const frx wg = x_add_lazy<FrX>(x_repack_in<FrX>(w[j]), gamma);
+            const frx sg = x_repack_in<FrX>(ld(&stage[stage_slot<QE>(t * QE + j)]));
+            num[j] = x_mul<FrX>(x_add_lazy<FrX>(wg, id), num[j]);
+            den[j] = x_mul<FrX>(x_add_lazy<FrX>(wg, x_mul<FrX>(sg, beta)), den[j]);
+            if (j + 1 < QE) id = x_mul<FrX>(id, omega);
         }
-        // wire a against the identity (beta w^i) and S_sigma1; then b (k1) and S_sigma2; then c (k2) and S_sigma3
-        stage_in(p.a, base, p.n, false, stage, a, zero);
-        stage_in(p.s1, base, p.n, false, stage, s, zero);
-#pragma unroll
-        for (uint32_t j = 0; j < PE; ++j) {
-            const fr_t ag = fr_add(a[j], p.gamma);
-            num[j] = fr_add(ag, bw[j]);
-            den[j] = fr_add(ag, fr_mul(p.beta, s[j]));
-        }
-        stage_in(p.b, base, p.n, false, stage, a, zero);
-        stage_in(p.s2, base, p.n, false, stage, s, zero);
-#pragma unroll
-        for (uint32_t j = 0; j < PE; ++j) {
-            const fr_t bg = fr_add(a[j], p.gamma);
-            num[j] = fr_mul(num[j], fr_add(bg, fr_mul(p.k1, bw[j])));
-            den[j] = fr_mul(den[j], fr_add(bg, fr_mul(p.beta, s[j])));
-        }
-        stage_in(p.c, base, p.n, false, stage, a, zero);
-        stage_in(p.s3, base, p.n, false, stage, s, zero);
-#pragma unroll
-        for (uint32_t j = 0; j < PE; ++j) {
-            const fr_t cg = fr_add(a[j], p.gamma);
-            num[j] = fr_mul(num[j], fr_add(cg, fr_mul(p.k2, bw[j])));
-            den[j] = fr_mul(den[j], fr_add(cg, fr_mul(p.beta, s[j])));
-        }
+        __syncthreads();
     }
     // only i < n - 1 enter the product (prover.rs:271); the rest count as the ratio 1
     bool zero_den = false;
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) {
+#pragma clang loop unroll(full)
+    for (uint32_t j = 0; j < QE; ++j) {
         if (i0 + j + 1 >= p.n) {
             num[j] = one;
             den[j] = one;
-        } else if (f_is_zero<FrP>(den[j])) {
+        } else if (x_is_zero16<FrX>(den[j])) {
             zero_den = true;
             den[j] = one;
         }
     }
     if (zero_den) atomicOr(flag, 1u);
-    // batch inversion: products before each element inside the lane, lane products scanned from both sides
-    fr_t pre[PE];
-    fr_t run = one;
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) {
-        pre[j] = run;
-        run = fr_mul(run, den[j]);
+    // inside the lane: num[j] <- product of the numerators before j; den[j] <- product of the denominators from j on
+    frx run_n = one, run_d = one;
+#pragma clang loop unroll(full)
+    for (uint32_t j = 0; j < QE; ++j) {
+        const frx v = num[j];
+        num[j] = run_n;
+        run_n = x_mul<FrX>(run_n, v);
     }
-    fr_t all;
-    const fr_t before = wg_exclusive_scan<1>(run, part, &all);
-    // suffix products of the lanes after this one: the same scan on the mirrored lane order
-    st(&part2[PT - 1 - t], run);
-    __syncthreads();
-    const fr_t mirrored = ld(&part2[t]);
-    __syncthreads();
-    fr_t all2;
-    const fr_t after_m = wg_exclusive_scan<1>(mirrored, part, &all2);   // lane t holds the product of the lanes after lane 255 - t
-    st(&part2[PT - 1 - t], after_m);
-    __syncthreads();
-    const fr_t after = ld(&part2[t]);
-    __shared__ fr_t inv_all;
-    if (t == 0) st(&inv_all, fr_inverse(all));
-    __syncthreads();
-    fr_t inv = fr_mul(fr_mul(ld(&inv_all), before), after);   // 1 / (this lane's product)
-    fr_t ratio[PE];
-#pragma unroll
-    for (uint32_t jj = 0; jj < PE; ++jj) {
-        const uint32_t j = PE - 1 - jj;
-        ratio[j] = fr_mul(num[j], fr_mul(inv, pre[j]));
-        inv = fr_mul(inv, den[j]);
+#pragma clang loop unroll(full)
+    for (uint32_t jj = 0; jj < QE; ++jj) {
+        const uint32_t j = QE - 1 - jj;
+        run_d = x_mul<FrX>(run_d, den[j]);
+        den[j] = run_d;
     }
-    // exclusive prefix products of the ratios inside the workgroup
-    run = one;
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) {
-        pre[j] = run;
-        run = fr_mul(run, ratio[j]);
+    // over the lanes: wavefront 0 takes the numerators (lanes before), wavefront 1 the denominators (lanes after)
+    st_slot(&slots_n[lane_slot(t)], run_n);
+    st_slot(&slots_d[lane_slot(t)], run_d);
+    __syncthreads();
+    if (t < 64) wave_scan_totals(slots_n, true, &tile_tot[0]);
+    else if (t < 128) wave_scan_totals(slots_d, false, &tile_tot[1]);
+    __syncthreads();
+    // lane factor, with the conversion to the stored form folded in
+    frx kout;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 9; ++i) kout.l[i] = FrX::kout(i);
+    const frx lane = x_mul<FrX>(x_mul<FrX>(ld_slot(&slots_n[lane_slot(t)]), ld_slot(&slots_d[lane_slot(t)])), kout);
+    const frx tn = ld_slot(&tile_tot[0]), td = ld_slot(&tile_tot[1]);
+    __syncthreads();
+    fr_t out[QE];
+#pragma clang loop unroll(full)
+    for (uint32_t j = 0; j < QE; ++j)
+        out[j] = x_repack_out<FrX>(x_canon2<FrX>(x_mul<FrX>(x_mul<FrX>(num[j], den[j]), lane)));
+    stage_out<QE>(local, base, p.n, false, stage, out);
+    if (t == 0) {
+        st(tot_n + blockIdx.x, x_to_sat<FrX>(tn));
+        st(tot_d + blockIdx.x, x_to_sat<FrX>(td));
     }
-    fr_t total;
-    const fr_t off = wg_exclusive_scan<1>(run, part, &total);
-#pragma unroll
-    for (uint32_t j = 0; j < PE; ++j) pre[j] = fr_mul(off, pre[j]);
-    stage_out(local, base, p.n, false, stage, pre);
-    if (t == 0) st(totals + blockIdx.x, total);
 }
 
-// out[i] = offs[i / 2048] * local[i]   (OP 1)   or   offs[...] + local[i]   (OP 0)
-template <int OP>
+// offs[w] = (prod_{v<w} tot_n[v]) (prod_{v>w} tot_d[v]), *den_all = prod_v tot_d[v]; one workgroup of 1024 lanes, lane t
+// taking a run of consecutive tiles.  tot_n and tot_d are overwritten.
+__global__ __launch_bounds__(1024) void perm_middle_kernel(fr_t* tot_n, fr_t* tot_d, uint32_t m, fr_t* __restrict__ offs,
+                                                           fr_t* __restrict__ den_all) {
+    __shared__ fr_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (m + 1023) / 1024;
+    const uint32_t lo = min(m, tid * per), hi = min(m, lo + per);
+    fr_t before_n, after_d;
+    // prefix over the numerators
+    {
+        fr_t run = f_one<FrP>();
+        for (uint32_t k = lo; k < hi; ++k) {
+            const fr_t v = ld(tot_n + k);
+            st(tot_n + k, run);
+            run = fr_mul(run, v);
+        }
+        st(&part[tid], run);
+        __syncthreads();
+        fr_t incl = run;
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            fr_t v = f_one<FrP>();
+            if (tid >= off) v = ld(&part[tid - off]);
+            __syncthreads();
+            incl = fr_mul(v, incl);
+            st(&part[tid], incl);
+            __syncthreads();
+        }
+        before_n = tid > 0 ? ld(&part[tid - 1]) : f_one<FrP>();
+        __syncthreads();
+    }
+    // suffix over the denominators
+    {
+        fr_t run = f_one<FrP>();
+        for (uint32_t k = hi; k > lo; --k) {
+            const fr_t v = ld(tot_d + k - 1);
+            st(tot_d + k - 1, run);
+            run = fr_mul(run, v);
+        }
+        st(&part[tid], run);
+        __syncthreads();
+        fr_t incl = run;
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            fr_t v = f_one<FrP>();
+            if (tid + off < 1024) v = ld(&part[tid + off]);
+            __syncthreads();
+            incl = fr_mul(v, incl);
+            st(&part[tid], incl);
+            __syncthreads();
+        }
+        after_d = tid < 1023 ? ld(&part[tid + 1]) : f_one<FrP>();
+        if (tid == 0) st(den_all, incl);   // nonzero: zero denominators were replaced
+    }
+    const fr_t lane = fr_mul(before_n, after_d);
+    for (uint32_t k = lo; k < hi; ++k) st(offs + k, fr_mul(fr_mul(ld(tot_n + k), ld(tot_d + k)), lane));
+}
+
+// out[i] = scale * offs[i >> tile_log] * local[i]
 __global__ __launch_bounds__(256) void apply_offsets_kernel(const fr_t* __restrict__ local, const fr_t* __restrict__ offs, uint32_t n,
-                                                            fr_t* __restrict__ out) {
+                                                            uint32_t tile_log, fr_t scale, fr_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    st(out + i, scan_op<OP>(ld(offs + (i >> 11)), ld(local + i)));
+    st(out + i, fr_mul(fr_mul(ld(offs + (i >> tile_log)), scale), ld(local + i)));
 }
 
 // ---- exclusive scans over Fr: OP 0 = add, 1 = mul; reverse: suffix instead of prefix ----
@@ -409,21 +433,41 @@ void pow_tables(Ctx* ctx, const host::fr_h* points, uint32_t count, uint32_t max
     HIP_CHECK(hipGetLastError());
 }
 
-static constexpr size_t PERM_LDS_BYTES = (STAGE_ELEMS + 2 * PT) * sizeof(fr_t);
+static constexpr size_t PERM_LDS_BYTES = Q_STAGE * sizeof(fr_t);
+static_assert((2 * 320 + 2) * sizeof(frx_slot) <= PERM_LDS_BYTES, "the lane totals reuse the staging area");
 
-void perm_grand_product(Ctx* ctx, const PermArgs& p, fr_t* z_out, fr_t* local, uint32_t* flag, DevBuf<fr_t>& totals) {
-    static bool attr_set[64] = {};
-    if (!attr_set[ctx->device & 63]) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(perm_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)PERM_LDS_BYTES));
-        attr_set[ctx->device & 63] = true;
+static PermScalar perm_scalar(const host::fr_h& mont) {
+    const host::fr_h t = host::Fr::mul(mont, host::Fr::from_u64(32));
+    PermScalar r;
+    memset(&r, 0, sizeof(r));
+    frx_words_from_u64(t.l, r.w);
+    return r;
+}
+
+void perm_grand_product(Ctx* ctx, const PermArgs& args, fr_t* z_out, fr_t* local, uint32_t* flag, DevBuf<fr_t>& totals) {
+    PermArgs p = args;
+    {
+        host::fr_h beta, k1, k2, omega;
+        memcpy(beta.l, p.beta.l, 32); memcpy(k1.l, p.k1.l, 32); memcpy(k2.l, p.k2.l, 32); memcpy(omega.l, p.omega.l, 32);
+        p.beta_x = perm_scalar(beta);
+        p.beta32_x = perm_scalar(host::Fr::mul(beta, host::Fr::from_u64(32)));
+        p.k1_x = perm_scalar(k1);
+        p.k2_x = perm_scalar(k2);
+        p.omega_x = perm_scalar(omega);
     }
-    const uint32_t wgs = (p.n + PW - 1) / PW;
-    totals.ensure(wgs);
-    hipLaunchKernelGGL(perm_fused_kernel, dim3(wgs), dim3(PT), PERM_LDS_BYTES, ctx->stream, p, local, totals.p, flag);
+    const uint32_t wgs = (p.n + QW - 1) / QW;
+    PLONK_REQUIRE(wgs <= (1u << 22), "grand product: too many tiles");
+    totals.ensure(3 * (size_t)wgs + 1);
+    fr_t *tot_n = totals.p, *tot_d = totals.p + wgs, *offs = totals.p + 2 * (size_t)wgs, *den_all = totals.p + 3 * (size_t)wgs;
+    hipLaunchKernelGGL(perm_tile_kernel, dim3(wgs), dim3(PT), PERM_LDS_BYTES, ctx->stream, p, local, tot_n, tot_d, flag);
     HIP_CHECK(hipGetLastError());
-    scan_totals<1>(ctx, totals.p, wgs);
-    hipLaunchKernelGGL(apply_offsets_kernel<1>, dim3((p.n + 255) / 256), dim3(256), 0, ctx->stream, local, totals.p, p.n, z_out);
+    hipLaunchKernelGGL(perm_middle_kernel, dim3(1), dim3(1024), 0, ctx->stream, tot_n, tot_d, wgs, offs, den_all);
+    HIP_CHECK(hipGetLastError());
+    host::fr_h den;
+    HIP_CHECK(hipMemcpyAsync(&den, den_all, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(apply_offsets_kernel, dim3((p.n + 255) / 256), dim3(256), 0, ctx->stream, local, offs, p.n, QW_LOG,
+                       to_dev(host::Fr::inv(den)), z_out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -438,7 +482,7 @@ __global__ __launch_bounds__(256) void eval_partial_kernel(EvalArgs a, fr_t* __r
     fr_t h = f_zero<FrP>();
     if (first < len) {
         const fr_t step = ld(a.lo[q] + PT);   // x^256
-#pragma unroll
+#pragma clang loop unroll(full)
         for (uint32_t kk = 0; kk < PE; ++kk) {
             const uint32_t i = first + (PE - 1 - kk) * PT;
             h = fr_mul(h, step);
@@ -497,7 +541,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs a, fr_t* __res
     for (uint32_t k = 0; k < a.count; ++k) {
         if (i < a.len[k]) {
             frx s;
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int w = 0; w < 9; ++w) s.l[w] = a.s[k].w[w];
             acc = x_add_lazy<FrX>(acc, x_mul<FrX>(x_repack_in<FrX>(ld(a.p[k] + i)), s));
         }
@@ -536,7 +580,7 @@ __global__ __launch_bounds__(256) void div_local_kernel(const fr_t* __restrict__
     fr_t pw = f_one<FrP>();
     if (r0 < len) pw = tab_pow(z.lo, z.hi, len - 1 - r0);
     fr_t run = f_zero<FrP>();
-#pragma unroll
+#pragma clang loop unroll(full)
     for (uint32_t j = 0; j < PE; ++j) {
         const fr_t s = fr_mul(v[j], pw);      // zero beyond the end
         pw = fr_mul(pw, z_inv);
@@ -545,7 +589,7 @@ __global__ __launch_bounds__(256) void div_local_kernel(const fr_t* __restrict__
     }
     fr_t total;
     const fr_t off = wg_exclusive_scan<0>(run, part, &total);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (uint32_t j = 0; j < PE; ++j) v[j] = fr_add(v[j], off);
     stage_out(local, base, len, true, stage, v);
     if (t == 0) st(totals + blockIdx.x, total);
