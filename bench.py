@@ -173,7 +173,7 @@ def main():
     # PLONK_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks: the ranks
     # share the devices and the library stages its all-gathers through the host (RCCL wants a GPU per rank)
     backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
+    if backend != "nccl" or os.environ.get("PLONK_BENCH_SHARE_GPUS"):
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -187,7 +187,30 @@ def main():
     n = 1 << k
     t0 = time.time()
     circ = circuits.SyntheticCircuit(k)
-    comm = sharded.Communicator(ctx, dist, rank, world, kind="rccl" if backend == "nccl" else "callback") if world > 1 else None
+    comm, exchange_note = None, None
+    if world > 1:
+        kind = "rccl" if backend == "nccl" else "callback"
+        if kind == "rccl":
+            # RCCL over xGMI; if it cannot be brought up on ANY rank, all ranks agree (over gloo) to stage the
+            # all-gathers through the host instead, and the JSON line says so
+            try:
+                comm = sharded.Communicator(ctx, dist, rank, world, kind="rccl")
+                failure = ""
+            except Exception as e:   # noqa: BLE001 -- reported below
+                failure = "%s: %s" % (type(e).__name__, e)
+            ok = torch.tensor([0 if failure else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                notes = [None] * world
+                dist.all_gather_object(notes, failure)
+                exchange_note = "RCCL unavailable (%s): all-gathers staged through the host over gloo" % \
+                    "; ".join(sorted({x for x in notes if x}))
+                if comm is not None:
+                    comm.close()
+                comm = None
+                kind = "callback"
+        if comm is None:
+            comm = sharded.Communicator(ctx, dist, rank, world, kind=kind)
     lo, hi = sharded.point_range(n + 11, rank, world)
     srs = pa.Srs.from_tau(circ.tau, n + 10, ctx=ctx) if world == 1 else pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
     pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
@@ -281,9 +304,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic 2^%d-gate mul/add chain, 3-wire PLONK prove, witness "
                                    "resident in HBM, SRS/proving key preloaded" % k,
-                       "parallelism": "1 GPU" if world == 1 else "msm point-range sharding over %d GPUs, shares all-gathered on "
-                                      "the device (%s)" % (world, comm.kind),
-                       "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest},
+                       "parallelism": "1 GPU" if world == 1 else "MSMs sharded by point range and round 3 by evaluation point over %d GPUs, shares all-gathered %s" % (
+                                          world, "on the device by RCCL" if comm.kind == "rccl" else "through the host (gloo)"),
+                       "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest,
+                       **({"exchange_note": exchange_note} if exchange_note else {})},
             "ntt_gbps": round(ntt_rate / 1e9, 2), "ntt_ms_coset_2^%d" % log4: round(ntt_ms, 4),
             "msm_mpoints_per_s": round(n / msm_s / 1e6, 3), "msm_ms_2^%d" % k: round(msm_s * 1e3, 3),
             # dominant kernel of the proof: the MSM bucket accumulation (over half of the GPU time).  Its bound is the
