@@ -303,61 +303,69 @@ __global__ __launch_bounds__(256, 2) void perm_tile_kernel(PermArgs p, fr_t* __r
     }
 }
 
+// Inclusive scans by products over the lanes of a wavefront, both at once: n over the lanes up to this one, d over
+// the lanes from this one on (2^steps_log lanes take part; the lanes beyond must hold one in d).
+__device__ __forceinline__ void wave_scan_pair(frx& n, frx& d, uint32_t steps_log) {
+    const uint32_t l = threadIdx.x & 63u;
+#pragma unroll 1
+    for (uint32_t off = 1; off < (1u << steps_log); off <<= 1) {
+        const frx o_n = x_shfl(n, off, true), o_d = x_shfl(d, off, false);
+        const frx m_n = x_mul<FrX>(o_n, n), m_d = x_mul<FrX>(o_d, d);
+        if (l >= off) n = m_n;
+        if (l + off < 64) d = m_d;
+    }
+}
+
 // offs[w] = (prod_{v<w} tot_n[v]) (prod_{v>w} tot_d[v]), *den_all = prod_v tot_d[v]; one workgroup of 1024 lanes, lane t
-// taking a run of consecutive tiles.  tot_n and tot_d are overwritten.
+// taking a run of consecutive tiles; the lanes' products are scanned inside each wavefront by shuffles, the 16
+// wavefronts' by the first one.  tot_n and tot_d are overwritten.
 __global__ __launch_bounds__(1024) void perm_middle_kernel(fr_t* tot_n, fr_t* tot_d, uint32_t m, fr_t* __restrict__ offs,
                                                            fr_t* __restrict__ den_all) {
-    __shared__ fr_t part[1024];
-    const uint32_t tid = threadIdx.x;
+    __shared__ frx_slot wave_tot[2][16], wave_off[2][16];
+    const uint32_t tid = threadIdx.x, l = tid & 63u, wave = tid >> 6;
     const uint32_t per = (m + 1023) / 1024;
     const uint32_t lo = min(m, tid * per), hi = min(m, lo + per);
-    fr_t before_n, after_d;
-    // prefix over the numerators
-    {
-        fr_t run = f_one<FrP>();
-        for (uint32_t k = lo; k < hi; ++k) {
-            const fr_t v = ld(tot_n + k);
-            st(tot_n + k, run);
-            run = fr_mul(run, v);
-        }
-        st(&part[tid], run);
-        __syncthreads();
-        fr_t incl = run;
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            fr_t v = f_one<FrP>();
-            if (tid >= off) v = ld(&part[tid - off]);
-            __syncthreads();
-            incl = fr_mul(v, incl);
-            st(&part[tid], incl);
-            __syncthreads();
-        }
-        before_n = tid > 0 ? ld(&part[tid - 1]) : f_one<FrP>();
-        __syncthreads();
+    const frx one = x_one<FrX>();
+    // inside the lane's run: tot_n[k] <- numerators before k, tot_d[k] <- denominators after k
+    frx run_n = one, run_d = one;
+#pragma unroll 1
+    for (uint32_t k = lo; k < hi; ++k) {
+        const frx v = x_from_sat<FrX>(ld(tot_n + k));
+        st(tot_n + k, x_to_sat<FrX>(run_n));
+        run_n = x_mul<FrX>(run_n, v);
     }
-    // suffix over the denominators
-    {
-        fr_t run = f_one<FrP>();
-        for (uint32_t k = hi; k > lo; --k) {
-            const fr_t v = ld(tot_d + k - 1);
-            st(tot_d + k - 1, run);
-            run = fr_mul(run, v);
-        }
-        st(&part[tid], run);
-        __syncthreads();
-        fr_t incl = run;
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            fr_t v = f_one<FrP>();
-            if (tid + off < 1024) v = ld(&part[tid + off]);
-            __syncthreads();
-            incl = fr_mul(v, incl);
-            st(&part[tid], incl);
-            __syncthreads();
-        }
-        after_d = tid < 1023 ? ld(&part[tid + 1]) : f_one<FrP>();
-        if (tid == 0) st(den_all, incl);   // nonzero: zero denominators were replaced
+#pragma unroll 1
+    for (uint32_t k = hi; k > lo; --k) {
+        const frx v = x_from_sat<FrX>(ld(tot_d + k - 1));
+        st(tot_d + k - 1, x_to_sat<FrX>(run_d));
+        run_d = x_mul<FrX>(run_d, v);
     }
-    const fr_t lane = fr_mul(before_n, after_d);
-    for (uint32_t k = lo; k < hi; ++k) st(offs + k, fr_mul(fr_mul(ld(tot_n + k), ld(tot_d + k)), lane));
+    frx incl_n = run_n, incl_d = run_d;
+    wave_scan_pair(incl_n, incl_d, 6);
+    frx ex_n = x_shfl(incl_n, 1, true), ex_d = x_shfl(incl_d, 1, false);
+    if (l == 0) ex_n = one;
+    if (l == 63) ex_d = one;
+    if (l == 63) st_slot(&wave_tot[0][wave], incl_n);
+    if (l == 0) st_slot(&wave_tot[1][wave], incl_d);
+    __syncthreads();
+    if (wave == 0) {
+        frx a = l < 16 ? ld_slot(&wave_tot[0][l]) : one, b = l < 16 ? ld_slot(&wave_tot[1][l]) : one;
+        wave_scan_pair(a, b, 4);
+        frx ea = x_shfl(a, 1, true);
+        const frx eb = x_shfl(b, 1, false);   // lane 15 reads the one of lane 16
+        if (l == 0) ea = one;
+        if (l < 16) {
+            st_slot(&wave_off[0][l], ea);
+            st_slot(&wave_off[1][l], eb);
+        }
+        if (l == 0) st(den_all, x_to_sat<FrX>(b));   // nonzero: zero denominators were replaced
+    }
+    __syncthreads();
+    const frx before_n = x_mul<FrX>(ld_slot(&wave_off[0][wave]), ex_n), after_d = x_mul<FrX>(ld_slot(&wave_off[1][wave]), ex_d);
+    const frx lane = x_mul<FrX>(before_n, after_d);
+#pragma unroll 1
+    for (uint32_t k = lo; k < hi; ++k)
+        st(offs + k, x_to_sat<FrX>(x_mul<FrX>(x_mul<FrX>(x_from_sat<FrX>(ld(tot_n + k)), x_from_sat<FrX>(ld(tot_d + k))), lane)));
 }
 
 // out[i] = scale * offs[i >> tile_log] * local[i]
