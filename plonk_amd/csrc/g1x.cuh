@@ -279,6 +279,62 @@ __device__ __forceinline__ PairPt pair_identity() {
     return a;
 }
 
+// ---- one addition by a QUAD of neighbouring lanes: lane j of the quad holds coordinate j of X, Y, ZZ, ZZZ ----
+// add-2008-s laid out four products deep (a pair needs seven, a lane fourteen):
+//     level 1:  U1 = X1 ZZ2   | S1 = Y1 ZZZ2    | U2 = X2 ZZ1 | S2 = Y2 ZZZ1
+//               P = U2 - U1 on lane 2, R = S2 - S1 on lane 3
+//     level 2:  ZZ1 ZZ2       | ZZZ1 ZZZ2       | PP = P^2    | RR = R^2
+//     level 3:  Q = U1 PP     | -               | PPP = P PP  | ZZ3 = ZZ1 ZZ2 PP
+//               X3 = RR - PPP - 2Q on lane 3
+//     level 4:  ZZZ3 = ZZZ1 ZZZ2 PPP | S1 PPP   | -           | R (Q - X3)
+//               Y3 = R (Q - X3) - S1 PPP on lane 1
+// Values cross lanes by quad-permute moves.  For the reduction trees, where the length of one addition's
+// instruction stream is what counts.
+constexpr int quad_ctrl(int s0, int s1, int s2, int s3) { return s0 | (s1 << 2) | (s2 << 4) | (s3 << 6); }
+template <int CTRL>
+__device__ __forceinline__ fqx quad_perm(const fqx& a) { return pair_bcast<CTRL>(a); }
+template <int J>
+__device__ __forceinline__ fqx quad_from(const fqx& a) { return pair_bcast<quad_ctrl(J, J, J, J)>(a); }
+__device__ __forceinline__ bool quad_is_inf(const fqx& v) {   // ZZ = 0 marks the identity; lane 2 holds ZZ
+    const int z = x_limbs_zero<FqX>(v) ? 1 : 0;
+    return __builtin_amdgcn_mov_dpp(z, quad_ctrl(2, 2, 2, 2), 0xf, 0xf, true) != 0;
+}
+__device__ __forceinline__ fqx quad_identity() { return x_zero<FqX>(); }
+
+// a += b; the four lanes of a quad call it together; j = lane & 3
+__device__ __forceinline__ void quad_add(fqx& a, const fqx& b, uint32_t j) {
+    if (quad_is_inf(b)) return;
+    if (quad_is_inf(a)) {
+        a = b;
+        return;
+    }
+    const bool upper = j >= 2;
+    const fqx m1 = qmul(a, quad_perm<quad_ctrl(2, 3, 0, 1)>(b));
+    const fqx D = x_sub<FqX, 2>(m1, quad_perm<quad_ctrl(0, 1, 0, 1)>(m1));   // lane 2: P, lane 3: R (< 4p)
+    const int dz = x_is_zero16<FqX>(D) ? 1 : 0;
+    if (__builtin_amdgcn_mov_dpp(dz, quad_ctrl(2, 2, 2, 2), 0xf, 0xf, true)) {   // P = 0: the same or opposite points
+        PtX fa, fb;
+        fa.x = quad_from<0>(a); fa.y = quad_from<1>(a); fa.zz = quad_from<2>(a); fa.zzz = quad_from<3>(a);
+        fb.x = quad_from<0>(b); fb.y = quad_from<1>(b); fb.zz = quad_from<2>(b); fb.zzz = quad_from<3>(b);
+        ptx_add<MulInline>(fa, fb);
+        a = pair_sel(upper, pair_sel(j == 3, fa.zzz, fa.zz), pair_sel(j == 1, fa.y, fa.x));
+        return;
+    }
+    const fqx m2 = qmul(pair_sel(upper, D, quad_perm<quad_ctrl(2, 3, 2, 3)>(a)),
+                        pair_sel(upper, D, quad_perm<quad_ctrl(2, 3, 2, 3)>(b)));
+    const fqx PP = quad_from<2>(m2);
+    const fqx m3 = qmul(pair_sel(j == 2, D, pair_sel(j == 3, quad_from<0>(m2), m1)), PP);
+    const fqx PPP = quad_from<2>(m3), Q = quad_from<0>(m3);
+    const fqx X3 = x_sub_sub2<FqX, 6>(m2, PPP, Q);        // lane 3: RR - PPP - 2Q (< 8p)
+    const fqx Dd = x_sub<FqX, 8>(Q, X3);                  // lane 3: Q - X3
+    const fqx m4 = qmul(pair_sel(j == 0, quad_from<1>(m2), pair_sel(j == 3, D, m1)), pair_sel(j == 3, Dd, PPP));
+    const fqx Y3 = x_sub<FqX, 2>(quad_from<3>(m4), m4);   // lane 1: R (Q - X3) - S1 PPP (< 4p)
+    a = pair_sel(upper, pair_sel(j == 3, quad_from<0>(m4), quad_from<3>(m3)), pair_sel(j == 1, Y3, quad_from<3>(X3)));
+}
+
+__device__ __forceinline__ fqx ld_quad(const g1x_xyzz_t* q, uint32_t j) { return ldx(&q->x + j); }
+__device__ __forceinline__ void st_quad(g1x_xyzz_t* q, const fqx& a, uint32_t j) { stx(&q->x + j, a); }
+
 __device__ __forceinline__ AffX ld_affx(const g1x_affine_t* p) {
     AffX r;
     r.x = ldx(&p->x);

@@ -592,45 +592,44 @@ __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __rest
 //          Col_lo = sum_hi R[hi][lo]; a high bit is a bit of hi and goes through the row sums
 //          Row_hi = sum_lo R[hi][lo].  Two adds per chunk instead of one per chunk and bit.
 //          6b: one workgroup per row (R and A) or column; 6c: one workgroup per quantity. ----
-// Sum of `count` points src[index(k)] over a workgroup of LANES lanes = LANES / 2 pairs, every
-// addition run by a pair (pair_add): each pair first adds its share, then the pairs' sums are folded
+// Sum of `count` points src[index(k)] over a workgroup of LANES lanes = LANES / 4 quads, every
+// addition run by a quad (quad_add): each quad first adds its share, then the quads' sums are folded
 // through LDS.  Both phases go through ONE expansion of the addition: in these short kernels a good
 // part of the time is the first pass over its straight-line code, so a second copy would cost
-// nearly as much again.  Result in pair 0 (lanes 0 and 1).
+// nearly as much again.  Result in quad 0 (lanes 0..3, lane j holding coordinate j).
 template <uint32_t LANES, class Index>
-__device__ __forceinline__ PairPt reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
-                                                g1x_xyzz_t* red, uint32_t tid) {
-    constexpr uint32_t PAIRS = LANES / 2;
-    const uint32_t pid = tid >> 1;
-    const bool odd = (tid & 1u) != 0;
-    const uint32_t n_serial = (count + PAIRS - 1) / PAIRS;
+__device__ __forceinline__ fqx reduce_points(const g1x_xyzz_t* __restrict__ src, uint32_t count, Index index,
+                                             g1x_xyzz_t* red, uint32_t tid) {
+    constexpr uint32_t QUADS = LANES / 4;
+    const uint32_t qid = tid >> 2, j = tid & 3u;
+    const uint32_t n_serial = (count + QUADS - 1) / QUADS;
     uint32_t levels = 0;
-    while ((1u << levels) < PAIRS) ++levels;
-    PairPt acc = pair_identity();
+    while ((1u << levels) < QUADS) ++levels;
+    fqx acc = quad_identity();
 #pragma unroll 1
     for (uint32_t step = 0; step < n_serial + levels; ++step) {
-        PairPt o = pair_identity();
+        fqx o = quad_identity();
         if (step < n_serial) {
-            const uint32_t k = pid + step * PAIRS;
-            if (k < count) o = ld_pair(src + index(k), odd);
+            const uint32_t k = qid + step * QUADS;
+            if (k < count) o = ld_quad(src + index(k), j);
         } else {
-            const uint32_t half = PAIRS >> (step - n_serial + 1);
-            st_pair(&red[pid], acc, odd);
+            const uint32_t half = QUADS >> (step - n_serial + 1);
+            st_quad(&red[qid], acc, j);
             __syncthreads();
-            if (pid < half) o = ld_pair(&red[pid + half], odd);
+            if (qid < half) o = ld_quad(&red[qid + half], j);
             __syncthreads();
         }
-        pair_add(acc, o, odd);   // adding the identity returns at once
+        quad_add(acc, o, j);   // adding the identity returns at once
     }
     return acc;
 }
 
-constexpr uint32_t ROWCOL_LANES = 128, MASKED_LANES = 512;
+constexpr uint32_t ROWCOL_LANES = 256, MASKED_LANES = 512;
 
 __global__ __launch_bounds__(ROWCOL_LANES) void msm_rowcol_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
                                                                    uint32_t m, uint32_t ml, g1x_xyzz_t* __restrict__ row,
                                                                    g1x_xyzz_t* __restrict__ arow, g1x_xyzz_t* __restrict__ col) {
-    __shared__ g1x_xyzz_t red[ROWCOL_LANES / 2];
+    __shared__ g1x_xyzz_t red[ROWCOL_LANES / 4];
     const uint32_t rows = 1u << (m - ml), cols = 1u << ml, chunks = 1u << m;
     const uint32_t w = blockIdx.y, tid = threadIdx.x;
     uint32_t job = blockIdx.x;
@@ -649,14 +648,14 @@ __global__ __launch_bounds__(ROWCOL_LANES) void msm_rowcol_kernel(const g1x_xyzz
         dst = col + (size_t)w * cols + job;
         first = job; stride = cols; count = rows;
     }
-    const PairPt acc = reduce_points<ROWCOL_LANES>(src, count, [=](uint32_t k) { return first + (size_t)k * stride; }, red, tid);
-    if (tid < 2) st_pair(dst, acc, tid == 1);
+    const fqx acc = reduce_points<ROWCOL_LANES>(src, count, [=](uint32_t k) { return first + (size_t)k * stride; }, red, tid);
+    if (tid < 4) st_quad(dst, acc, tid);
 }
 
 __global__ __launch_bounds__(MASKED_LANES) void msm_masked_kernel(const g1x_xyzz_t* __restrict__ row, const g1x_xyzz_t* __restrict__ arow,
                                                                    const g1x_xyzz_t* __restrict__ col, uint32_t m, uint32_t ml,
                                                                    g1_xyzz_t* __restrict__ out) {
-    __shared__ g1x_xyzz_t red[MASKED_LANES / 2];
+    __shared__ g1x_xyzz_t red[MASKED_LANES / 4];
     const uint32_t rows = 1u << (m - ml), cols = 1u << ml;
     const uint32_t q = blockIdx.x, nq = gridDim.x, w = blockIdx.y, tid = threadIdx.x;
     const g1x_xyzz_t* src;
@@ -669,19 +668,13 @@ __global__ __launch_bounds__(MASKED_LANES) void msm_masked_kernel(const g1x_xyzz
         src = row + (size_t)w * rows; count = rows >> 1; bit = q - 1 - ml;
     }
     // q > 0: the k-th index with bit `bit` set
-    const PairPt acc = reduce_points<MASKED_LANES>(src, count, [=](uint32_t k) -> size_t {
+    const fqx acc = reduce_points<MASKED_LANES>(src, count, [=](uint32_t k) -> size_t {
         return q == 0 ? k : (((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)));
     }, red, tid);
-    if (tid >= 2) return;
-    // back to the saturated form for the host: lane 0 holds X, ZZ, ZZZ, lane 1 holds Y
+    if (tid >= 4) return;
+    // back to the saturated form for the host: lane j holds coordinate j
     g1_xyzz_t* dst = out + (size_t)w * nq + q;
-    if (tid == 1) {
-        st(&dst->y, x_to_sat<FqX>(acc.p));
-    } else {
-        st(&dst->x, x_to_sat<FqX>(acc.p));
-        st(&dst->zz, x_to_sat<FqX>(acc.s));
-        st(&dst->zzz, x_to_sat<FqX>(acc.t));
-    }
+    st(&dst->x + tid, x_to_sat<FqX>(acc));
 }
 
 // saturated affine -> x-form affine
