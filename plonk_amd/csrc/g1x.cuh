@@ -101,6 +101,26 @@ __device__ __forceinline__ void ptx_madd(PtX& acc, const AffX& q, bool neg = fal
     acc.zzz = qmul(acc.zzz, PPP);
 }
 
+// acc = +-a +- b for two affine points (mmadd-2008-s: 4M + 2S, the two products of Y3 under one reduction -- about
+// half a mixed addition).  False, acc untouched, when one of them is the identity or they share x.
+__device__ __forceinline__ bool ptx_from_two(PtX& acc, const AffX& a, bool neg_a, const AffX& b, bool neg_b) {
+    if (affx_is_inf(a) || affx_is_inf(b)) return false;
+    const fqx P = x_sub<FqX, 2>(b.x, a.x);                               // < 4p
+    if (x_is_zero16<FqX>(P)) return false;
+    const fqx y1 = neg_a ? x_sub<FqX, 2>(x_zero<FqX>(), a.y) : a.y;      // < 4p
+    const fqx y2 = neg_b ? x_sub<FqX, 2>(x_zero<FqX>(), b.y) : b.y;
+    const fqx R = x_sub<FqX, 4>(y2, y1);                                 // < 8p
+    const fqx PP = qsqr(P);
+    const fqx PPP = qmul(P, PP);
+    const fqx Q = qmul(a.x, PP);
+    const fqx X3 = x_sub_sub2<FqX, 6>(qsqr(R), PPP, Q);                  // R^2 - PPP - 2Q, < 8p
+    acc.y = MulInline::mul_sub(R, x_sub<FqX, 8>(Q, X3), y1, PPP);        // < 2p
+    acc.x = X3;
+    acc.zz = PP;
+    acc.zzz = PPP;
+    return true;
+}
+
 // acc += q (add-2008-s: 12M + 2S)
 template <class M = MulInline>
 __device__ __forceinline__ void ptx_add(PtX& acc, const PtX& q) {

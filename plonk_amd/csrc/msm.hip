@@ -373,12 +373,27 @@ __global__ __launch_bounds__(256) void msm_bucket_kernel(const g1x_affine_t* __r
     const uint32_t cnt = counts[gid];
     const uint32_t* src = sorted + offsets[gid];
     PtX acc = ptx_identity();
+    const AffX no_point = AffX{x_zero<FqX>(), x_zero<FqX>()};
     // the next point is fetched (a random 128-byte read) while the current one is added
     uint32_t e_next = cnt ? src[0] : 0u;
-    AffX nxt = cnt ? load_point(points, e_next) : AffX{x_zero<FqX>(), x_zero<FqX>()};
+    AffX nxt = cnt ? load_point(points, e_next) : no_point;
     bool neg_next = entry_neg(e_next);
     e_next = cnt > 1 ? src[1] : 0u;
-    for (uint32_t k = 0; k < cnt; ++k) {
+    uint32_t k = 0;
+    if (cnt >= 2) {
+        // the first two points are both affine: their sum costs about half a mixed addition.  Should it not apply
+        // (an identity, equal x) the lane simply starts the loop below at its first point.
+        const AffX second = load_point(points, e_next);
+        const uint32_t e2 = cnt > 2 ? src[2] : 0u;
+        const AffX third = cnt > 2 ? load_point(points, e2) : no_point;   // on its way while the first sum is taken
+        if (ptx_from_two(acc, nxt, neg_next, second, entry_neg(e_next))) {
+            k = 2;
+            nxt = third;
+            neg_next = entry_neg(e2);
+            e_next = cnt > 3 ? src[3] : 0u;
+        }
+    }
+    for (; k < cnt; ++k) {
         const AffX p = nxt;
         const bool neg = neg_next;
         if (k + 1 < cnt) {
