@@ -586,13 +586,15 @@ __global__ __launch_bounds__(256) void msm_chunk_kernel(const g1x_xyzz_t* __rest
     const g1x_xyzz_t* B = buckets + (size_t)w * nbk + ((size_t)t << chunk_log);
     PtX running = ptx_identity(), acc = ptx_identity();
     // running += B_j, then acc += running: one expansion of the addition serves both (its ~55 KB of
-    // straight-line code is most of the instruction cache), the operands are switched around it
+    // straight-line code is most of the instruction cache), the operands are switched around it.
+    // The next bucket is fetched while acc += running runs: a lane is alone on its SIMD here.
+    PtX next = ld_ptx(B + ((1u << chunk_log) - 1u));
 #pragma unroll 1
     for (uint32_t step = 0; step < (2u << chunk_log); ++step) {
         const bool take = (step & 1u) == 0;
         PtX x = take ? running : acc;
-        PtX y = running;
-        if (take) y = ld_ptx(B + ((1u << chunk_log) - 1u - (step >> 1)));
+        PtX y = take ? next : running;
+        if (!take && step + 1 < (2u << chunk_log)) next = ld_ptx(B + ((1u << chunk_log) - 2u - (step >> 1)));
         ptx_add<MulInline>(x, y);
         if (take) running = x;
         else acc = x;
