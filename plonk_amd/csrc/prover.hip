@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void quotient_kernel(QuotientArgs q) {
     frx x = ld_scaled(q.x_lo + (i & ((1u << q.log_l) - 1u)));
     if (i >> q.log_l) x = x_mul<FrX>(x, ld_tw(q.x_hi + (i >> q.log_l)));
     // gate: q_M a b + q_L a + q_R b + q_O c + q_C + PI   (each product below 2p, limbs normalised)
-    frx gate = x_mul<FrX>(x_mul<FrX>(ld_scaled(q.pk_ext + j), a), b);
-    gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + N + j), a));
+    // (q_M b + q_L) a: with the tables' scaling (q_M by 2^10, q_L by 2^5) the inner sum is already on one scale
+    frx gate = x_mul<FrX>(x_add_lazy<FrX>(x_mul<FrX>(ld_scaled(q.pk_ext + j), b), ld_scaled(q.pk_ext + N + j)), a);
     gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 2 * N + j), b));
     gate = x_add_lazy<FrX>(gate, x_mul<FrX>(ld_scaled(q.pk_ext + 3 * N + j), c));
     gate = x_add_lazy<FrX>(gate, ld_scaled(q.pk_ext + 4 * N + j));
