@@ -214,7 +214,15 @@ def main():
     lo, hi = sharded.point_range(n + 11, rank, world)
     srs = pa.Srs.from_tau(circ.tau, n + 10, ctx=ctx) if world == 1 else pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
     pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
-    prover = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi))
+    # up to 2^21 gates a rank's share of a commitment is latency-bound: the rounds that commit two / three
+    # polynomials then place each commitment on a group of ranks (one larger MSM per rank instead of two / three small ones)
+    groups = {}
+    if world > 1 and k <= 21:
+        for b in (2, 3):
+            if world >= b:
+                glo, ghi = sharded.group_range(n + 11, rank, world, b)
+                groups[b] = (pa.Srs.from_tau_range(circ.tau, glo, ghi, ctx=ctx), (glo, ghi))
+    prover = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi), groups=groups)
     setup_s = time.time() - t0
 
     def barrier():
@@ -306,7 +314,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic 2^%d-gate mul/add chain, 3-wire PLONK prove, witness "
                                    "resident in HBM, SRS/proving key preloaded" % k,
-                       "parallelism": "1 GPU" if world == 1 else "MSMs sharded by point range and round 3 by evaluation point over %d GPUs, shares all-gathered %s" % (
+                       "parallelism": "1 GPU" if world == 1 else "MSMs sharded by point range%s and round 3 by evaluation point over %d GPUs, shares all-gathered %s" % (
+                                          " (commitments of a round placed on groups of ranks)" if groups else "",
                                           world, "on the device by RCCL" if comm.kind == "rccl" else "through the host (gloo)"),
                        "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest,
                        **({"exchange_note": exchange_note} if exchange_note else {})},

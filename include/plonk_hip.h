@@ -189,8 +189,8 @@ int32_t plonk_comm_create_rccl(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BY
 int32_t plonk_comm_create_callback(plonk_ctx* ctx, uint32_t rank, uint32_t world, plonk_allgather_fn allgather,
                                    void* user, plonk_comm** out);
 /* Measurement aid: one rank of a `world`-rank proof running alone on its GPU.  Its all-gathers return
- * copies of the rank's own record in every slot (device-to-device), and the balanced split of
- * `total_points` (the first total_points % world ranks one point more) for the coverage check: the
+ * copies of the rank's own record in every slot (device-to-device), and the balanced splits of
+ * `total_points` (the first total_points % parts members one point more) for the coverage check: the
  * proof is NOT valid, the rank's device work is what it would be among real peers. */
 int32_t plonk_comm_create_loopback(plonk_ctx* ctx, uint32_t rank, uint32_t world, size_t total_points, plonk_comm** out);
 void plonk_comm_destroy(plonk_comm* comm);
@@ -205,6 +205,22 @@ int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plon
                                   plonk_comm* comm, const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev,
                                   const plonk_fr* c_evals_dev, const plonk_fr* public_inputs, size_t n_public_inputs,
                                   const plonk_fr blinding[11], plonk_proof* out);
+/* The same with the commitments of a round placed by groups of ranks.  srs[0] / lo[0] is the rank's slice as in
+ * plonk_prove_3wire_sharded (used by the rounds that commit one polynomial: all ranks tile the range).  srs[1]
+ * and srs[2], each optional (NULL) but present on all ranks or on none, are its slices for the rounds that
+ * commit two (the openings) and three (the wires; the quotient parts) polynomials at once: commitment k of such
+ * a round is computed by the ranks r with r % b == k alone, whose slices must tile the point range among them
+ * (checked) -- each rank runs one MSM over 1/ceil(world / b) of the points instead of b MSMs over 1/world.
+ * For circuits whose shares would be latency-bound; needs world >= b.  No counterpart in the single-process
+ * reference (prover.rs:181-244, :545-552, :819-820 commit one polynomial after the other). */
+typedef struct plonk_shard_slices {
+    const plonk_srs* srs[3];
+    uint64_t lo[3];
+} plonk_shard_slices;
+int32_t plonk_prove_3wire_grouped(plonk_ctx* ctx, const plonk_pk* pk, const plonk_shard_slices* slices, plonk_comm* comm,
+                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
+                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
+                                  plonk_proof* out);
 /* Sum of n affine points on the host (combining per-rank partial commitments). */
 int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out);
 /* Window width c (bits) the MSM uses for n points: W = ceil(256/c) windows of 2^(c-1) buckets. */

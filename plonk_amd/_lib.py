@@ -40,6 +40,10 @@ class G2(C.Structure):
                 ("infinity", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
+class ShardSlices(C.Structure):
+    _fields_ = [("srs", C.c_void_p * 3), ("lo", C.c_uint64 * 3)]
+
+
 class Vk(C.Structure):
     _fields_ = [("n", C.c_uint64)] + [(k, G1) for k in ("q_m_comm", "q_l_comm", "q_r_comm", "q_o_comm", "q_c_comm",
                                                         "s_sigma1_comm", "s_sigma2_comm", "s_sigma3_comm")] + \
@@ -106,6 +110,7 @@ SIGNATURES = {
     "plonk_comm_destroy": (None, [_vp]),
     "plonk_comm_stats": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "plonk_prove_3wire_grouped": (_i32, [_vp, _vp, C.POINTER(ShardSlices), _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "plonk_g1_sum": (_i32, [_vp, _sz, _vp]),
     "plonk_msm_window_bits": (_u32, [_sz]),
     "plonk_msm_set_timing": (_i32, [_vp, _i32]),

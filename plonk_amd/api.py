@@ -529,16 +529,24 @@ class Prover:
     eleven blinding scalars from thread_rng (prover.rs:189-194, 310-312, 537-538); here the caller
     passes them (`blinding`), or they come from os.urandom."""
 
-    def __init__(self, wires, pk, srs, resident=False, comm=None, shard=None):
+    def __init__(self, wires, pk, srs, resident=False, comm=None, shard=None, groups=None):
         """comm/shard: multi-GPU proving (plonk_amd.sharded): `srs` is then this rank's slice
-        [shard[0], shard[1]) of g1_powers and `comm` a sharded.Communicator."""
+        [shard[0], shard[1]) of g1_powers and `comm` a sharded.Communicator.
+        groups: optional {2: (srs_slice, (lo, hi)), 3: (srs_slice, (lo, hi))} -- the rank's slices for the rounds
+        that commit 2 / 3 polynomials at once, whose commitments are then placed on groups of ranks
+        (sharded.group_range gives the ranges; plonk_prove_3wire_grouped)."""
         if comm is not None:
             if shard is None or len(shard) != 2 or shard[1] - shard[0] != len(srs):
                 raise PlonkError(_lib.PLONK_E_INVALID, "sharded proving needs shard=(lo, hi) with hi - lo = len(srs)")
+            for b, (g_srs, g_range) in (groups or {}).items():
+                if b not in (2, 3) or len(g_range) != 2 or g_range[1] - g_range[0] != len(g_srs):
+                    raise PlonkError(_lib.PLONK_E_INVALID, "groups needs {2 or 3: (srs slice, (lo, hi))} with hi - lo = len(slice)")
+        elif groups:
+            raise PlonkError(_lib.PLONK_E_INVALID, "groups without a communicator")
         self.pk, self.srs = pk, srs
         self.wires = [_as_limbs(w, pk.n) for w in wires]
         self.dev = None
-        self.comm, self.shard = comm, shard
+        self.comm, self.shard, self.groups = comm, shard, dict(groups or {})
         if resident or comm is not None:  # keep the witness in HBM: prove() then starts from device buffers
             ctx = pk.ctx
             self.dev = [ctx.alloc(w.nbytes) for w in self.wires]
@@ -561,7 +569,15 @@ class Prover:
         pis = (_lib.Fr * max(len(public_inputs), 1))(*[_fr_struct(p) for p in public_inputs])
         raw = _lib.Proof()
         ctx = self.pk.ctx
-        if self.comm is not None:
+        if self.comm is not None and self.groups:
+            sl = _lib.ShardSlices()
+            sl.srs[0], sl.lo[0] = self.srs.h.value, self.shard[0]
+            for b, (g_srs, g_range) in self.groups.items():
+                sl.srs[b - 1], sl.lo[b - 1] = g_srs.h.value, g_range[0]
+            ctx.check(lib.plonk_prove_3wire_grouped(ctx.h, self.pk.h, C.byref(sl), self.comm.h,
+                                                    self.dev[0], self.dev[1], self.dev[2],
+                                                    pis, len(public_inputs), bl, C.byref(raw)))
+        elif self.comm is not None:
             ctx.check(lib.plonk_prove_3wire_sharded(ctx.h, self.pk.h, self.srs.h, self.shard[0], self.comm.h,
                                                     self.dev[0], self.dev[1], self.dev[2],
                                                     pis, len(public_inputs), bl, C.byref(raw)))

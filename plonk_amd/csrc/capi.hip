@@ -449,6 +449,31 @@ int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plon
     API_END()
 }
 
+int32_t plonk_prove_3wire_grouped(plonk_ctx* ctx, const plonk_pk* pk, const plonk_shard_slices* slices, plonk_comm* comm,
+                                  const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev, const plonk_fr* c_evals_dev,
+                                  const plonk_fr* public_inputs, size_t n_public_inputs, const plonk_fr blinding[11],
+                                  plonk_proof* out) {
+    if (!ctx || !pk || !slices || !slices->srs[0] || !comm || !a_evals_dev || !b_evals_dev || !c_evals_dev || !blinding || !out)
+        return PLONK_E_INVALID;
+    if (n_public_inputs && !public_inputs) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Pk* k = reinterpret_cast<const Pk*>(pk);
+    const Srs* s = reinterpret_cast<const Srs*>(slices->srs[0]);
+    PLONK_REQUIRE(k->device == C_->device && s->device == C_->device, "prove: key or SRS lives on another device");
+    PLONK_REQUIRE(comm->ex->world > 1 || slices->lo[0] == 0, "prove: a single rank holds the whole point range");
+    ShardInfo sh;
+    sh.lo = slices->lo[0];
+    sh.ex = comm->ex.get();
+    for (int g = 0; g < 2; ++g) {
+        if (!slices->srs[g + 1]) continue;
+        sh.group_srs[g] = reinterpret_cast<const Srs*>(slices->srs[g + 1]);
+        sh.group_lo[g] = slices->lo[g + 1];
+        PLONK_REQUIRE(sh.group_srs[g]->device == C_->device, "prove: a group slice of the SRS lives on another device");
+    }
+    prove_3wire(C_, k, s, a_evals_dev, b_evals_dev, c_evals_dev, true, public_inputs, n_public_inputs, blinding, out, &sh);
+    API_END()
+}
+
 int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out) {
     if (!out || (n && !points)) return PLONK_E_INVALID;
     g1_from_host(g1_sum_affine(points, n), out);

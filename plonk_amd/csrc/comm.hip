@@ -91,18 +91,30 @@ struct CallbackExchange : Exchange {
 };
 
 // Measurement aid: rank `rank` of a `world`-rank proof running alone.  Every rank's slot of an all-gather is
-// filled with this rank's own record by device-to-device copies, except the 16-byte (first point, count)
-// records of the coverage check, which are made up as the balanced split of `total_points`.  The proofs that
-// come out are not valid; the device work of the rank (its shares of the MSMs, its class of round 3) is real.
+// filled with this rank's own record by device-to-device copies, except the 48-byte records of the coverage
+// check (first point and count of the rank's plain slice and of its slices for rounds of 2 and 3 commitments),
+// which are made up as the balanced splits of `total_points`.  The proofs that come out are not valid; the
+// device work of the rank (its shares of the MSMs, its class of round 3) is real.
 struct LoopbackExchange : Exchange {
     size_t total_points = 0;
+    static void split(size_t total, uint32_t index, uint32_t parts, uint64_t* first, uint64_t* count) {
+        const size_t base = total / parts, extra = total % parts;
+        *first = index * base + std::min<size_t>(index, extra);
+        *count = base + (index < extra ? 1 : 0);
+    }
     void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
-        if (nbytes == 2 * sizeof(uint64_t)) {
-            std::vector<uint64_t> rec(2 * (size_t)world);
-            const size_t base = total_points / world, extra = total_points % world;
+        if (nbytes == 6 * sizeof(uint64_t)) {
+            uint64_t mine[6];
+            HIP_CHECK(hipMemcpyAsync(mine, send_dev, sizeof(mine), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            std::vector<uint64_t> rec(6 * (size_t)world, 0);
             for (uint32_t r = 0; r < world; ++r) {
-                rec[2 * r] = r * base + std::min<size_t>(r, extra);
-                rec[2 * r + 1] = base + (r < extra ? 1 : 0);
+                split(total_points, r, world, &rec[6 * r], &rec[6 * r + 1]);
+                for (uint32_t g = 0; g < 2; ++g) {
+                    if (!mine[3 + 2 * g]) continue;   // this rank brings no slice for rounds of g + 2 commitments
+                    const uint32_t b = g + 2, k = r % b, members = (world - k + b - 1) / b;
+                    split(total_points, r / b, members, &rec[6 * r + 2 + 2 * g], &rec[6 * r + 3 + 2 * g]);
+                }
             }
             HIP_CHECK(hipMemcpyAsync(recv_dev, rec.data(), rec.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipStreamSynchronize(stream));

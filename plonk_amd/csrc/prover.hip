@@ -418,37 +418,56 @@ static bool sharded(const ShardInfo* shard) { return shard && shard->ex; }
 // one GPU, the slice of the rank's SRS points otherwise.  Coefficients past the last SRS point must be
 // zero: kzg.rs:232-238 strips trailing zeros before its length check and panics otherwise; here the
 // flag is raised, identically on every rank (they all hold the whole polynomial).
-static void commit_range(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev, const ShardInfo* shard,
+// The slice of the SRS a rank uses for commitment `index` of a round of `batch` commitments, where in the
+// coefficient vector it starts, and whether this rank takes part in that commitment at all.
+struct CommitSlice {
+    const Srs* srs;
+    size_t lo;
+    bool mine;
+};
+static CommitSlice commit_slice(const Srs* srs, const ShardInfo* shard, int batch, int index) {
+    CommitSlice c{srs, sharded(shard) ? shard->lo : 0, true};
+    if (!sharded(shard) || batch < 2 || batch > 3 || !shard->group_srs[batch - 2]) return c;
+    c.srs = shard->group_srs[batch - 2];
+    c.lo = shard->group_lo[batch - 2];
+    c.mine = shard->ex->rank % (uint32_t)batch == (uint32_t)index;
+    return c;
+}
+
+static void commit_range(Ctx* ctx, const CommitSlice& cs, const fr_t* coeffs, size_t len, uint32_t* flag_dev, const ShardInfo* shard,
                          size_t* lo, size_t* hi) {
-    const size_t end = sharded(shard) ? shard->global_end : srs->n;
+    const size_t end = sharded(shard) ? shard->global_end : cs.srs->n;
     if (len > end) poly_nonzero_check(ctx, coeffs, (uint32_t)end, (uint32_t)len, flag_dev);
     if (sharded(shard)) {
-        *lo = std::min(shard->lo, len);
-        *hi = std::min(shard->lo + srs->n, len);
+        *lo = std::min(cs.lo, len);
+        *hi = cs.mine ? std::min(cs.lo + cs.srs->n, len) : *lo;   // not this rank's commitment: an empty share
     } else {
         *lo = 0;
-        *hi = std::min(len, srs->n);
+        *hi = std::min(len, cs.srs->n);
     }
 }
 
 static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
                                   const ShardInfo* shard = nullptr, const MsmFiller& filler = nullptr) {
     size_t lo, hi;
-    commit_range(ctx, srs, coeffs, len, flag_dev, shard, &lo, &hi);
-    return msm_run(ctx, msm_points(srs), coeffs + lo, hi - lo, filler, sharded(shard) ? shard->ex : nullptr);
+    const CommitSlice cs = commit_slice(srs, shard, 1, 0);
+    commit_range(ctx, cs, coeffs, len, flag_dev, shard, &lo, &hi);
+    return msm_run(ctx, msm_points(cs.srs), coeffs + lo, hi - lo, filler, sharded(shard) ? shard->ex : nullptr);
 }
 
 // Several commitments against the same SRS, overlapped on the device (independent MSMs on
 // separate streams).  commit_add starts one as soon as its coefficients are ready on ctx->stream;
 // commit_finish collects them.  Sharded runs all-gather the ranks' shares inside the MSM.
+// `batch`: how many commitments the round will add (it selects the placement, see ShardInfo).
 static void commit_add(Ctx* ctx, const Srs* srs, MsmBatch& b, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
-                       const ShardInfo* shard) {
+                       const ShardInfo* shard, int batch) {
+    const CommitSlice cs = commit_slice(srs, shard, batch, b.count);
     if (b.count == 0) {
-        b.pts = msm_points(srs);
+        b.pts = msm_points(cs.srs);
         b.ex = sharded(shard) ? shard->ex : nullptr;
     }
     size_t lo, hi;
-    commit_range(ctx, srs, coeffs, len, flag_dev, shard, &lo, &hi);
+    commit_range(ctx, cs, coeffs, len, flag_dev, shard, &lo, &hi);
     msm_batch_add(ctx, b, coeffs + lo, hi - lo);
 }
 
@@ -461,29 +480,54 @@ static void commit_finish(Ctx* ctx, MsmBatch& b, const ShardInfo* shard, host::G
 static void commit_batch(Ctx* ctx, const Srs* srs, const fr_t* const* coeffs, const size_t* lens, int count,
                          uint32_t* flag_dev, const ShardInfo* shard, host::G1AffineH* out, const MsmFiller& filler = nullptr) {
     MsmBatch b;
-    for (int k = 0; k < count; ++k) commit_add(ctx, srs, b, coeffs[k], lens[k], flag_dev, shard);
+    for (int k = 0; k < count; ++k) commit_add(ctx, srs, b, coeffs[k], lens[k], flag_dev, shard, count);
     commit_finish(ctx, b, shard, out, filler);
 }
 
-// The ranks' SRS slices must tile [0, global_end) in rank order; every rank learns global_end.
+// The ranks' SRS slices must tile [0, global_end) in rank order; every rank learns global_end.  With placement
+// by groups all ranks or none bring the slices for a batch size b, and those of the ranks r = k mod b must tile
+// the same range, for every k < b.
 static void shard_check_coverage(Ctx* ctx, ProverWorkspace* ws, const Srs* srs, ShardInfo* shard) {
     Exchange* ex = shard->ex;
-    ws->xchg.ensure(2 + 2 * (size_t)ex->world);
-    const uint64_t mine[2] = {shard->lo, srs->n};
+    constexpr size_t REC = 6;   // (first point, points) of the plain slice and of the slices for b = 2, 3 (points = 0: none)
+    ws->xchg.ensure(REC + REC * (size_t)ex->world);
+    uint64_t mine[REC] = {shard->lo, srs->n, 0, 0, 0, 0};
+    for (int g = 0; g < 2; ++g) {
+        if (!shard->group_srs[g]) continue;
+        PLONK_REQUIRE(shard->group_srs[g]->n > 0, "prove: empty SRS slice for a group placement");
+        mine[2 + 2 * g] = shard->group_lo[g];
+        mine[3 + 2 * g] = shard->group_srs[g]->n;
+    }
     HIP_CHECK(hipMemcpyAsync(ws->xchg.p, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ex->allgather(ws->xchg.p, ws->xchg.p + 2, sizeof(mine), ctx->stream);
-    std::vector<uint64_t> all(2 * (size_t)ex->world);
-    HIP_CHECK(hipMemcpyAsync(all.data(), ws->xchg.p + 2, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    ex->allgather(ws->xchg.p, ws->xchg.p + REC, sizeof(mine), ctx->stream);
+    std::vector<uint64_t> all(REC * (size_t)ex->world);
+    HIP_CHECK(hipMemcpyAsync(all.data(), ws->xchg.p + REC, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    PLONK_REQUIRE(all[2 * ex->rank] == shard->lo && all[2 * ex->rank + 1] == srs->n,
+    PLONK_REQUIRE(memcmp(&all[REC * ex->rank], mine, sizeof(mine)) == 0,
                   "prove: the all-gather does not return this rank's record at its rank index");
     uint64_t next = 0;
     for (uint32_t r = 0; r < ex->world; ++r) {
-        PLONK_REQUIRE(all[2 * r] == next, "prove: the ranks' SRS slices do not tile the point range (gap or overlap)");
-        next += all[2 * r + 1];
+        PLONK_REQUIRE(all[REC * r] == next, "prove: the ranks' SRS slices do not tile the point range (gap or overlap)");
+        next += all[REC * r + 1];
     }
     shard->global_end = next;
+    for (uint32_t g = 0; g < 2; ++g) {
+        const uint32_t b = g + 2;
+        uint32_t have = 0;
+        for (uint32_t r = 0; r < ex->world; ++r) have += all[REC * r + 3 + 2 * g] != 0;
+        if (have == 0) continue;
+        PLONK_REQUIRE(have == ex->world, "prove: some ranks bring group slices and some do not");
+        PLONK_REQUIRE(ex->world >= b, "prove: fewer ranks than commitments in a group placement");
+        for (uint32_t k = 0; k < b; ++k) {
+            uint64_t at = 0;
+            for (uint32_t r = k; r < ex->world; r += b) {
+                PLONK_REQUIRE(all[REC * r + 2 + 2 * g] == at, "prove: the group slices of the ranks of one commitment do not tile the point range");
+                at += all[REC * r + 3 + 2 * g];
+            }
+            PLONK_REQUIRE(at == next, "prove: the group slices of the ranks of one commitment do not cover the point range");
+        }
+    }
 }
 
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
@@ -585,7 +629,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         const fr_h b2[2] = {bl[2 * k + 1], bl[2 * k]};  // blind poly [b2, b1] (:205-207)
         poly_blind(ctx, W[k], (uint32_t)n, b2, 2);
         poly_copy(ctx, CO[k], W[k], n + 2);
-        commit_add(ctx, srs, r1, CO[k], n + 2, ws->flag.p, shard);
+        commit_add(ctx, srs, r1, CO[k], n + 2, ws->flag.p, shard, 3);
     }
     commit_finish(ctx, r1, shard, comm, coset_abc);
     tr.absorb_g1("a_comm", comm[0]);
@@ -686,7 +730,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     }
     HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
     poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->tmp.p, ws->wq2.p, ws->totals);
-    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard);
+    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2);
     fr_h e6[6];
     {
         EvalArgs ea;
@@ -764,7 +808,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
-        commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard);
+        commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard, 2);
         host::G1AffineH w[2];
         commit_finish(ctx, openings, shard, w);
         comm[7] = w[1];   // W_zeta

@@ -30,6 +30,11 @@ struct ShardInfo {
     size_t lo = 0;
     Exchange* ex = nullptr;
     size_t global_end = 0;   // one past the last SRS point any rank holds (set by the prover)
+    // Optional placement by groups: group_srs[b - 2] is this rank's slice for the rounds that commit b = 2 or 3
+    // polynomials at once.  Commitment k of such a round is then computed by the ranks r with r % b == k alone,
+    // whose slices tile the point range among THEM: each rank runs one larger MSM instead of b small ones.
+    const Srs* group_srs[2] = {nullptr, nullptr};
+    size_t group_lo[2] = {0, 0};
 };
 
 Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plonk_fr* const sig[3], const host::fr_h& k1,

@@ -20,6 +20,16 @@ def point_range(n_points, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def group_range(n_points, rank, world, batch):
+    """The rank's point range when the `batch` commitments of a round are placed on groups of ranks:
+    commitment k belongs to the ranks r with r % batch == k, which split [0, n_points) among them in
+    rank order (plonk_prove_3wire_grouped).  Needs world >= batch."""
+    if world < batch:
+        raise ValueError("placement by groups needs at least as many ranks as commitments")
+    members = (world - rank % batch + batch - 1) // batch
+    return point_range(n_points, rank // batch, members)
+
+
 class HostAllGather:
     """All-gather of fixed-size byte records over torch.distributed with host tensors (gloo),
     callable from the C library as a plonk_allgather_fn."""

@@ -108,6 +108,15 @@ pub struct PlonkVk {
     pub k2: PlonkFr,
 }
 
+/// `plonk_shard_slices`: a rank's SRS slices for rounds committing one, two and three polynomials
+/// (`[1]`, `[2]` optional: null).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct PlonkShardSlices {
+    pub srs: [*const PlonkSrs; 3],
+    pub lo: [u64; 3],
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct PlonkMsmTiming {
@@ -182,6 +191,10 @@ extern "C" {
                                      comm: *mut PlonkComm, a_evals_dev: *const PlonkFr, b_evals_dev: *const PlonkFr,
                                      c_evals_dev: *const PlonkFr, public_inputs: *const PlonkFr, n_public_inputs: usize,
                                      blinding: *const PlonkFr, out: *mut PlonkProof) -> i32;
+    pub fn plonk_prove_3wire_grouped(ctx: *mut PlonkCtx, pk: *const PlonkPk, slices: *const PlonkShardSlices, comm: *mut PlonkComm,
+                                     a_evals_dev: *const PlonkFr, b_evals_dev: *const PlonkFr, c_evals_dev: *const PlonkFr,
+                                     public_inputs: *const PlonkFr, n_public_inputs: usize, blinding: *const PlonkFr,
+                                     out: *mut PlonkProof) -> i32;
     pub fn plonk_g1_sum(points: *const PlonkG1, n: usize, out: *mut PlonkG1) -> i32;
     pub fn plonk_msm_window_bits(n: usize) -> u32;
     pub fn plonk_msm_set_timing(ctx: *mut PlonkCtx, enable: i32) -> i32;

@@ -114,7 +114,15 @@ lo, hi = sharded.point_range(n + 11, rank, world)
 srs = pa.Srs.from_tau_range(tau, lo, hi, ctx=ctx)
 assert len(srs) == hi - lo
 pk = pa.ProvingKey(n, selectors, sigmas, k1, k2, positions, ctx=ctx)
-prover = pa.Prover(wires, pk, srs, resident=True, comm=comm, shard=(lo, hi))
+groups = {}
+if os.environ.get("PLONK_TEST_GROUPED") == "1":
+    # the commitments of the rounds with two / three polynomials placed on groups of ranks
+    for b in (2, 3):
+        if world >= b:
+            glo, ghi = sharded.group_range(n + 11, rank, world, b)
+            groups[b] = (pa.Srs.from_tau_range(tau, glo, ghi, ctx=ctx), (glo, ghi))
+    assert groups
+prover = pa.Prover(wires, pk, srs, resident=True, comm=comm, shard=(lo, hi), groups=groups)
 proof = prover.prove(pis, blinding)
 calls, nbytes = comm.stats()
 # the coverage check, one all-gather per commitment MSM, and -- when round 3 is sharded by evaluation
@@ -123,7 +131,7 @@ point_sharded = world & (world - 1) == 0
 assert calls == 1 + 9 + (1 if point_sharded else 0), calls
 assert comm.host.calls == calls
 if point_sharded:
-    assert nbytes == 16 + 9 * (64 + 256 * 192) + (4 * n // world) * 32, nbytes
+    assert nbytes == 48 + 9 * (64 + 256 * 192) + (4 * n // world) * 32, nbytes
 if want is not None:
     assert proof.to_bytes() == want, "sharded proof differs from the single-device proof"
 else:   # the digest test_prove_full_size_verifies pins for the single-device proof of this circuit
@@ -146,6 +154,18 @@ if case == "16" and world == 2:
         raise SystemExit("a too-short sharded SRS was accepted")
     except pa.PlonkError as e:
         assert e.code == pa._lib.PLONK_E_INVALID, e
+if groups and case == "14" and world == 4:
+    # group slices that leave a gap among the ranks of one commitment are refused
+    b = 3
+    glo, ghi = sharded.group_range(n + 11, rank, world, b)
+    shift = 1 if rank == 3 else 0   # rank 3 is the second member of commitment 0's group
+    bad = dict(groups)
+    bad[b] = (pa.Srs.from_tau_range(tau, glo + shift, ghi, ctx=ctx), (glo + shift, ghi))
+    try:
+        pa.Prover(wires, pk, srs, resident=True, comm=comm, shard=(lo, hi), groups=bad).prove(pis, blinding)
+        raise SystemExit("a gap in a group's point range was accepted")
+    except pa.PlonkError as e:
+        assert e.code == pa._lib.PLONK_E_INVALID and "group" in str(e), e
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -156,7 +176,8 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,case", [(2, "16"), (2, "20"), (4, "10"), (8, "14"), (3, "10"), (2, "pi9"), (8, "pi6")])
+@pytest.mark.parametrize("world,case", [(2, "16"), (2, "20"), (4, "10"), (8, "14"), (3, "10"), (2, "pi9"), (8, "pi6"),
+                                        (2, "16g"), (3, "10g"), (4, "14g"), (8, "16g"), (8, "pi6g")])
 def test_sharded_prove_ranks_on_one_gpu(tmp_path, world, case):
     """plonk_prove_3wire_sharded with several ranks on cuda:0 (gloo + the callback communicator for the
     exchange): every rank holds an SRS slice with its own window table; the ranks' shares of every MSM
@@ -164,14 +185,18 @@ def test_sharded_prove_ranks_on_one_gpu(tmp_path, world, case):
     (transforms of size 4n / world on the rank's residue class of the coset, quotient slices
     all-gathered and recombined -- with 8 ranks z(wX) lives on another rank's class).  All ranks emit
     the single-device proof: golden bytes (2^10 / 2^14 / 2^16), the pinned digest of the 2^20-gate
-    configuration, the oracle's bytes for circuits with public inputs."""
+    configuration, the oracle's bytes for circuits with public inputs.  Cases ending in "g": the rounds
+    that commit two / three polynomials place each commitment on the ranks r = k mod 2 / 3
+    (plonk_prove_3wire_grouped), every rank bringing a slice per placement."""
+    grouped = case.endswith("g")
+    case = case.rstrip("g")
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER % {"root": ROOT})
     procs = []
-    port = 29600 + world * 16 + sum(map(ord, case)) % 16
+    port = 29600 + world * 32 + sum(map(ord, case)) % 16 + (16 if grouped else 0)
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PLONK_TEST_CASE=case)
+                   PLONK_TEST_CASE=case, PLONK_TEST_GROUPED="1" if grouped else "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -205,7 +230,7 @@ def test_rccl_communicator_single_rank(ctx):
     want = [e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json"))) if e["name"] == "synthetic_2^16"][0]
     assert proof.to_bytes().hex() == want["proof"]
     calls, nbytes = comm.stats()
-    assert calls == 10 and nbytes == 16 + 9 * (64 + 256 * 192)   # one rank: round 3 is not sharded
+    assert calls == 10 and nbytes == 48 + 9 * (64 + 256 * 192)   # one rank: round 3 is not sharded
     comm.close()
 
 

@@ -2,7 +2,8 @@
 on the GPU behind the library's loopback communicator (plonk_comm_create_loopback).  The proof that
 comes out is wrong; the time the rank spends on its shares of the MSMs, transforms and quotient is what
 a real rank spends, minus the exchange itself.  Development aid for the scaling table.
-usage: dev_shard_timing.py <log_n> <world> [reps] [rank]"""
+usage: dev_shard_timing.py <log_n> <world> [reps] [rank] [grouped]
+(grouped = 1: the rounds with two / three commitments place them on groups of ranks)"""
 import ctypes as C
 import os
 import sys
@@ -34,12 +35,18 @@ comm.h, comm.world = h, world
 lo, hi = ranges[rank]
 srs = pa.Srs.from_tau_range(circ.tau, lo, hi, ctx=ctx)
 pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, (), ctx=ctx)
-prover = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi))
+groups = {}
+if len(sys.argv) > 5 and sys.argv[5] == "1":
+    for b in (2, 3):
+        if world >= b:
+            glo, ghi = sharded.group_range(n + 11, rank, world, b)
+            groups[b] = (pa.Srs.from_tau_range(circ.tau, glo, ghi, ctx=ctx), (glo, ghi))
+prover = pa.Prover(circ.wires, pk, srs, resident=True, comm=comm, shard=(lo, hi), groups=groups)
 prover.prove([], circ.blinding)
 ctx.sync()
 t = time.perf_counter()
 for _ in range(reps):
     prover.prove([], circ.blinding)
 ctx.sync()
-print("2^%d gates, rank %d of %d: %.2f ms per proof without the exchange (which moves %.1f MiB per rank and proof)" %
-      (k, rank, world, (time.perf_counter() - t) / reps * 1e3, (9 * 49216 * (world - 1) + 4 * n * 32 * (world - 1) // world) / 2**20))
+print("2^%d gates, rank %d of %d%s: %.2f ms per proof without the exchange (which moves %.1f MiB per rank and proof)" %
+      (k, rank, world, " (grouped)" if groups else "", (time.perf_counter() - t) / reps * 1e3, (9 * 49216 * (world - 1) + 4 * n * 32 * (world - 1) // world) / 2**20))
