@@ -77,6 +77,29 @@ def test_sharded_commit_exchange_gloo(tmp_path):
         assert "rank %d ok" % rank in out
 
 
+def test_group_ranges_tile_the_points():
+    """sharded.group_range: for every batch size b the ranks r = k mod b split [0, n_points) among them in
+    rank order, for every k < b (what plonk_prove_3wire_grouped checks on the device side)."""
+    from plonk_amd import sharded
+    for n_points in (27, 75, 1035, (1 << 20) + 11):
+        for world in (2, 3, 4, 5, 8, 16):
+            for b in (2, 3):
+                if world < b:
+                    with pytest.raises(ValueError):
+                        sharded.group_range(n_points, 0, world, b)
+                    continue
+                for k in range(b):
+                    at = 0
+                    for r in range(k, world, b):
+                        lo, hi = sharded.group_range(n_points, r, world, b)
+                        assert lo == at and hi >= lo
+                        at = hi
+                    assert at == n_points
+            tiles = [sharded.point_range(n_points, r, world) for r in range(world)]
+            assert tiles[0][0] == 0 and tiles[-1][1] == n_points
+            assert all(tiles[i][1] == tiles[i + 1][0] for i in range(world - 1))
+
+
 GPU_WORKER = r'''
 import hashlib, json, os, random, sys
 sys.path.insert(0, %(root)r)
