@@ -641,7 +641,7 @@ __device__ __forceinline__ fqx reduce_points(const g1x_xyzz_t* __restrict__ src,
     return acc;
 }
 
-constexpr uint32_t ROWCOL_LANES = 256, MASKED_LANES = 512;
+constexpr uint32_t ROWCOL_LANES = 128, MASKED_LANES = 512;
 
 __global__ __launch_bounds__(ROWCOL_LANES) void msm_rowcol_kernel(const g1x_xyzz_t* __restrict__ A, const g1x_xyzz_t* __restrict__ R,
                                                                    uint32_t m, uint32_t ml, g1x_xyzz_t* __restrict__ row,
