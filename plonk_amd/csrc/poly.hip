@@ -667,6 +667,18 @@ void poly_blind(Ctx* ctx, fr_t* coeffs, uint32_t n, const host::fr_h* bl, uint32
     HIP_CHECK(hipGetLastError());
 }
 
+// coeffs[idx] += *v (or -= *v), v in device memory: no round trip through the host for a value only the device needs
+__global__ void poke_from_kernel(fr_t* coeffs, uint32_t idx, const fr_t* __restrict__ v, int subtract) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const fr_t c = ld(coeffs + idx), d = ld(v);
+        st(coeffs + idx, subtract ? fr_sub(c, d) : fr_add(c, d));
+    }
+}
+void poly_poke_from(Ctx* ctx, fr_t* coeffs, uint32_t idx, const fr_t* v_dev, bool subtract) {
+    hipLaunchKernelGGL(poke_from_kernel, dim3(1), dim3(64), 0, ctx->stream, coeffs, idx, v_dev, subtract ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+}
+
 void poly_poke(Ctx* ctx, fr_t* coeffs, uint32_t idx, const host::fr_h& v, bool subtract) {
     hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(64), 0, ctx->stream, coeffs, idx, to_dev(v), subtract ? 1 : 0);
     HIP_CHECK(hipGetLastError());

@@ -541,6 +541,9 @@ host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev,
     return r;
 }
 
+// The kernels that detect a zero denominator (round 2) or an over-long polynomial (rounds 3, 5) raise a flag and
+// carry on with harmless values; the flag is read once, at the end of the proof, instead of with a stream
+// synchronisation after every round.
 static void check_flag(Ctx* ctx, ProverWorkspace* ws) {
     uint32_t f = 0;
     HIP_CHECK(hipMemcpyAsync(&f, ws->flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -664,7 +667,6 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         class_evaluate(ctx, s, W[3], n + 3, ps, ps.s_q, ps.c_q, SL[3]);
         if (ps.q2 != ps.q) class_evaluate(ctx, s, W[3], n + 3, ps, ps.s_q2, ps.c_q2, SL[4]);   // z(w X): the class of i + 4
     });
-    check_flag(ctx, ws);
     tr.absorb_g1("z_comm", comm[3]);
     const fr_h alpha = tr.squeeze_challenge("alpha");
 
@@ -710,7 +712,6 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         const size_t cl[3] = {n + 1, n + 1, n + 6};
         commit_batch(ctx, srs, cp, cl, 3, ws->flag.p, shard, comm + 4);
     }
-    check_flag(ctx, ws);
     tr.absorb_g1("t_lo_comm", comm[4]);
     tr.absorb_g1("t_mid_comm", comm[5]);
     tr.absorb_g1("t_hi_comm", comm[6]);
@@ -802,10 +803,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         memset(&ea, 0, sizeof(ea));
         ea.coeffs[0] = ws->wnum.p; ea.len[0] = wlen; ea.lo[0] = tabs[0].lo; ea.hi[0] = tabs[0].hi;
         poly_eval_batch(ctx, ea, 1, ws->evals.p + 6, ws->partial);
-        fr_h at_zeta;
-        HIP_CHECK(hipMemcpyAsync(&at_zeta, ws->evals.p + 6, sizeof(fr_t), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        poly_poke(ctx, ws->wnum.p, 0, at_zeta, true);
+        poly_poke_from(ctx, ws->wnum.p, 0, ws->evals.p + 6, true);   // the value stays on the device: nobody else needs it
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
         commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard, 2);
