@@ -42,6 +42,11 @@ struct NttPassArgs {
     // step twiddles of a non-last sweep p: one table per later sweep q, entry [i_q][k_p] =
     // w_N^(k_p M_p * i_q S_q) (times the coset factors that depend on i_q or k_p alone)
     const frx_slot* pair_tab[NTT_MAX_PASSES - 1];
+    // the product of the tables from index merged_from on, entry [k_p][low merged_bits bits of the lower
+    // index] -- consecutive outputs read consecutive entries: one product per element instead of one per
+    // later sweep (nullable)
+    const frx_slot* merged_tab;
+    uint32_t merged_from, merged_bits;
     uint32_t pair_shift[NTT_MAX_PASSES - 1];   // log2 S_q: where i_q sits in the lower index
     uint32_t pair_mask[NTT_MAX_PASSES - 1];    // N_q - 1
     uint32_t n_pairs;
@@ -242,12 +247,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
             // step twiddles: for every later sweep q the factor w_N^(k M_p * i_q S_q), i_q read off
             // the lower index (this is also what brings the element back below 2p)
             const uint32_t lo = lo_base + c;
+            addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
+            const uint32_t separate = p.merged_tab ? p.merged_from : p.n_pairs;
 #pragma unroll 1
-            for (uint32_t j = 0; j < p.n_pairs; ++j) {
+            for (uint32_t j = 0; j < separate; ++j) {
                 const uint32_t iq = (lo >> p.pair_shift[j]) & p.pair_mask[j];
                 x = x_mul<FrX>(x, ld_tw(p.pair_tab[j] + (((size_t)iq << R) + k)));
             }
-            addr = ((size_t)hi << (R + p.log_s)) + ((size_t)k << p.log_s) + lo;
+            if (p.merged_tab) x = x_mul<FrX>(x, ld_tw(p.merged_tab + (((size_t)k << p.merged_bits) + (lo & ((1u << p.merged_bits) - 1u)))));
         }
         st(out + addr, x_repack_out<FrX>(x));
     }
@@ -286,11 +293,36 @@ __global__ __launch_bounds__(256) void ntt_table_kernel(frx_slot* __restrict__ o
     q[2] = make_uint4(x.l[8], 0u, 0u, 0u);
 }
 
+// merged[k][lo] = prod_j t_j[i_j(lo)][k] over 2 or 3 step-twiddle tables of one sweep (t[2] nullable)
+struct MergeArgs {
+    const frx_slot* t[3];
+    uint32_t shift[3], mask[3];
+    uint32_t R, bits;   // k < 2^R, lo < 2^bits
+};
+__global__ __launch_bounds__(256) void ntt_merge_kernel(frx_slot* __restrict__ out, MergeArgs m) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;   // the grid covers 2^(R + bits) exactly
+    const uint32_t k = idx >> m.bits, lo = idx & ((1u << m.bits) - 1u);
+    frx x = x_mul<FrX>(ld_tw(m.t[0] + (((size_t)((lo >> m.shift[0]) & m.mask[0]) << m.R) + k)),
+                       ld_tw(m.t[1] + (((size_t)((lo >> m.shift[1]) & m.mask[1]) << m.R) + k)));
+    if (m.t[2]) x = x_mul<FrX>(x, ld_tw(m.t[2] + (((size_t)((lo >> m.shift[2]) & m.mask[2]) << m.R) + k)));
+    x = x_canon2<FrX>(x);
+    uint4* q = reinterpret_cast<uint4*>(out + idx);
+    q[0] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    q[1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    q[2] = make_uint4(x.l[8], 0u, 0u, 0u);
+}
+
+// a merged table has at most this many entries (48 bytes each)
+static constexpr uint32_t NTT_MERGED_MAX_LOG = 24;
+
 struct NttPlan {
     uint32_t log_n = 0, flags = 0, n_pass = 0;
     uint32_t R[NTT_MAX_PASSES] = {0, 0, 0, 0};
     const frx_slot* sub_tw = nullptr;
     const frx_slot* pair[NTT_MAX_PASSES][NTT_MAX_PASSES] = {};   // [p][q], p < q: step twiddles
+    // sweep p with two or more later sweeps: the step twiddles of the sweeps from merged_q0[p] on in one table
+    const frx_slot* merged[NTT_MAX_PASSES] = {};
+    uint32_t merged_q0[NTT_MAX_PASSES] = {0, 0, 0, 0};
     const frx_slot *pre = nullptr, *post = nullptr;   // first sweep's input scale (forward coset), last sweep's output scale (inverse)
     DevBuf<frx_slot> arena;   // owns the tables, unless they were placed in memory the caller provided
     host::fr_h shift;
@@ -342,6 +374,21 @@ static void plan_geometry(NttPlan* pl, uint32_t log_n, uint32_t flags) {
     pl->n_pass = P;
 }
 
+// log2 S_q = log2 (N_{q+1} ... N_P)
+static uint32_t plan_log_s(const NttPlan* pl, uint32_t q) {
+    uint32_t ls = 0;
+    for (uint32_t j = q + 1; j < pl->n_pass; ++j) ls += pl->R[j];
+    return ls;
+}
+// Sweep p merges the step twiddles of the later sweeps q >= q0 into one table [k_p][i_q0 .. i_P]: all of
+// them when that table is small enough, else all but the next sweep's; 0 = no merged table.
+static uint32_t plan_merge_from(const NttPlan* pl, uint32_t p) {
+    const uint32_t P = pl->n_pass;
+    for (uint32_t q0 = p + 1; q0 + 1 < P; ++q0)
+        if (pl->R[p] + plan_log_s(pl, q0 - 1) <= NTT_MERGED_MAX_LOG) return q0;
+    return 0;
+}
+
 // 48-byte slots the tables of a plan take
 static size_t plan_table_slots(const NttPlan* pl) {
     const bool inverse = pl->flags & NTT_INVERSE, coset = pl->flags & NTT_COSET;
@@ -351,6 +398,10 @@ static size_t plan_table_slots(const NttPlan* pl) {
     if (inverse) slots += (size_t)1 << pl->R[P - 1];
     for (uint32_t p = 0; p + 1 < P; ++p)
         for (uint32_t q = p + 1; q < P; ++q) slots += (size_t)1 << (pl->R[p] + pl->R[q]);
+    for (uint32_t p = 0; p + 2 < P; ++p) {
+        const uint32_t q0 = plan_merge_from(pl, p);
+        if (q0) slots += (size_t)1 << (pl->R[p] + plan_log_s(pl, q0 - 1));
+    }
     return slots;
 }
 
@@ -423,6 +474,28 @@ static void plan_build_tables(NttPlan* pl, const host::fr_h& shift, frx_slot* me
             pl->pair[p][q] = gen(one, gi, gk, step, pl->R[p], pl->R[q]);
         }
     }
+    for (uint32_t p = 0; p < NTT_MAX_PASSES; ++p) pl->merged[p] = nullptr;
+    for (uint32_t p = 0; p + 2 < P; ++p) {
+        const uint32_t q0 = plan_merge_from(pl, p);
+        pl->merged_q0[p] = q0;
+        if (!q0) continue;
+        MergeArgs m;
+        memset(&m, 0, sizeof(m));
+        for (uint32_t q = q0; q < P; ++q) {
+            m.t[q - q0] = pl->pair[p][q];
+            m.shift[q - q0] = log_S[q];
+            m.mask[q - q0] = (1u << pl->R[q]) - 1u;
+        }
+        m.R = pl->R[p];
+        m.bits = log_S[q0 - 1];
+        const uint32_t log_count = m.R + m.bits;
+        frx_slot* dst = cursor;
+        cursor += (size_t)1 << log_count;
+        if (log_count >= 8) hipLaunchKernelGGL(ntt_merge_kernel, dim3(1u << (log_count - 8)), dim3(256), 0, stream, dst, m);
+        else hipLaunchKernelGGL(ntt_merge_kernel, dim3(1), dim3(1u << log_count), 0, stream, dst, m);
+        HIP_CHECK(hipGetLastError());
+        pl->merged[p] = dst;
+    }
 }
 
 static constexpr uint32_t PLAN_SHIFT_SLOTS = 4;   // coset generators cached side by side per (size, direction)
@@ -479,6 +552,9 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         a.post = last ? pl->post : nullptr;
         a.sub_tw = pl->sub_tw;
         a.n_pairs = P - 1 - p;
+        a.merged_tab = pl->merged[p];
+        a.merged_from = pl->merged[p] ? pl->merged_q0[p] - (p + 1) : 0;
+        a.merged_bits = pl->merged[p] ? plan_log_s(pl, pl->merged_q0[p] - 1) : 0;
         {
             uint32_t ls = log_s;   // log2 S_p; S_q for q > p follows by peeling R[q]
             for (uint32_t q = p + 1; q < P; ++q) {
