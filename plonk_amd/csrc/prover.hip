@@ -263,22 +263,52 @@ __global__ __launch_bounds__(256) void class_gather_kernel(const fr_t* __restric
     st(out + row * M + j, ld(in + row * in_stride + (((size_t)j << log_g) + q)));
 }
 
-// t[k + m M] = sum_q coef[m][q] F[q][k], m < G: the inverse DFT across the ranks with its scaling folded in
+// t[k + m M] = 7^(-M m) / G * sum_q w_G^(-q m) F[q][k], m < G = 2^LOG_G: the inverse DFT across the ranks as
+// radix-2 butterflies in registers (decimation in time on the bit-reversed ranks), then one scaling per output --
+// (G/2) log2 G + G products per k instead of G^2, in the 29-bit-limb form (the values are only regrouped: the
+// transform is linear).  Only the multiplied operand of a butterfly is reduced; an element grows by at most 3p
+// per stage.
 static constexpr uint32_t SHARD_MAX_RANKS = 16;
-__global__ __launch_bounds__(256) void recombine_kernel(const fr_t* __restrict__ F, uint32_t G, uint32_t M,
-                                                        const fr_t* __restrict__ coef, fr_t* __restrict__ t) {
+struct RecombineConsts {
+    frx tw[SHARD_MAX_RANKS / 2];   // w_G^(-j), j < G/2
+    frx scale[SHARD_MAX_RANKS];    // 7^(-M m) / G
+};
+template <uint32_t LOG_G>
+__global__ __launch_bounds__(256) void recombine_kernel(const fr_t* __restrict__ F, uint32_t M,
+                                                        const RecombineConsts* __restrict__ consts, fr_t* __restrict__ t) {
+    constexpr uint32_t G = 1u << LOG_G;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
-    fr_t f[SHARD_MAX_RANKS];
-#pragma unroll
-    for (uint32_t q = 0; q < SHARD_MAX_RANKS; ++q)
-        if (q < G) f[q] = ld(F + (size_t)q * M + k);
+    frx a[G];
+#pragma clang loop unroll(full)
+    for (uint32_t q = 0; q < G; ++q) a[__brev(q) >> (32 - LOG_G)] = x_repack_in<FrX>(ld(F + (size_t)q * M + k));   // canonical
+#pragma clang loop unroll(full)
+    for (uint32_t s = 1; s <= LOG_G; ++s) {
+        const uint32_t m = 1u << s, half = m >> 1;
+#pragma clang loop unroll(full)
+        for (uint32_t base = 0; base < G; base += m) {
+#pragma clang loop unroll(full)
+            for (uint32_t j = 0; j < half; ++j) {
+                const frx u = a[base + j];
+                frx v = a[base + j + half];
+                // w_m^(-j) = w_G^(-j G/m); the first stage's operands are canonical and need no product
+                if (s > 1) {
+                    frx w;
+#pragma clang loop unroll(full)
+                    for (int l = 0; l < 9; ++l) w.l[l] = consts->tw[j << (LOG_G - s)].l[l];
+                    v = x_mul<FrX>(v, w);
+                }
+                a[base + j] = x_norm_u<FrX>(x_add_lazy<FrX>(u, v));
+                a[base + j + half] = x_norm_u<FrX>(x_sub_lazy<FrX, 3>(u, v));
+            }
+        }
+    }
+#pragma clang loop unroll(full)
     for (uint32_t m = 0; m < G; ++m) {
-        fr_t acc = f_zero<FrP>();
-#pragma unroll
-        for (uint32_t q = 0; q < SHARD_MAX_RANKS; ++q)
-            if (q < G) acc = fr_add(acc, fr_mul(ld(coef + m * G + q), f[q]));
-        st(t + (size_t)m * M + k, acc);
+        frx w;
+#pragma clang loop unroll(full)
+        for (int l = 0; l < 9; ++l) w.l[l] = consts->scale[m].l[l];
+        st(t + (size_t)m * M + k, x_repack_out<FrX>(x_canon2<FrX>(x_mul<FrX>(a[m], w))));
     }
 }
 
@@ -314,7 +344,7 @@ struct ProverWorkspace {
     DevBuf<fr_t> tq;         // [M]    t on the class, then F_q
     DevBuf<fr_t> fall;       // [G][M] the F_q of all ranks
     DevBuf<fr_t> ext_slice;  // [9][M] the key's coset tables on the class
-    DevBuf<fr_t> coef;       // [G][G] inverse DFT across the ranks, scaled
+    DevBuf<RecombineConsts> coef;   // twiddles and scalings of the inverse DFT across the ranks
     const Pk* slice_pk = nullptr;
     uint32_t slice_g = 0, slice_q = 0;
 };
@@ -360,24 +390,24 @@ static void point_shard_tables(Ctx* ctx, ProverWorkspace* ws, const Pk* pk, cons
     hipLaunchKernelGGL(class_gather_kernel, dim3((uint32_t)((M + 255) / 256), 9), dim3(256), 0, ctx->stream, pk->ext.p, n4,
                        ps.log_g, ps.q, (uint32_t)M, ws->ext_slice.p);
     HIP_CHECK(hipGetLastError());
-    // coef[m][q'] = 7^(-M m) / G * w_G^(-q' m), w_G = w_4n^M
+    // the inverse DFT across the ranks: w_G = w_4n^M; output m is scaled by 7^(-M m) / G
     const fr_h w4 = host::fr_root_of_unity(pk->log_n + 2);
     const fr_h wg_inv = Fr::inv(Fr::pow_u64(w4, M));
     const fr_h gm_inv = Fr::inv(Fr::pow_u64(Fr::from_u64(7), M));
-    const fr_h g_inv = Fr::inv(Fr::from_u64(ps.G));
-    std::vector<fr_h> coef((size_t)ps.G * ps.G);
-    fr_h scale = g_inv;
+    RecombineConsts rc;
+    memset(&rc, 0, sizeof(rc));
+    fr_h cur = Fr::one();
+    for (uint32_t j = 0; j < ps.G / 2; ++j) {
+        rc.tw[j] = to_frx(cur);
+        cur = Fr::mul(cur, wg_inv);
+    }
+    fr_h scale = Fr::inv(Fr::from_u64(ps.G));
     for (uint32_t m = 0; m < ps.G; ++m) {
-        const fr_h step = Fr::pow_u64(wg_inv, m);
-        fr_h cur = scale;
-        for (uint32_t q = 0; q < ps.G; ++q) {
-            coef[(size_t)m * ps.G + q] = cur;
-            cur = Fr::mul(cur, step);
-        }
+        rc.scale[m] = to_frx(scale);
         scale = Fr::mul(scale, gm_inv);
     }
-    ws->coef.ensure(coef.size());
-    HIP_CHECK(hipMemcpyAsync(ws->coef.p, coef.data(), coef.size() * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    ws->coef.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(ws->coef.p, &rc, sizeof(rc), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ws->slice_pk = pk;
     ws->slice_g = ps.G;
@@ -695,8 +725,15 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         quotient_run(ctx, pk, SL[0], SL[1], SL[2], SL[3], has_pi ? SL[5] : nullptr, alpha, beta, gamma, ws->tq.p, qs);
         ntt_run_shift(ctx, ws->tq.p, ps.log_m, NTT_COSET | NTT_INVERSE, ps.s_q, 1, 0);   // F_q = t mod (X^M - c_q)
         shard->ex->allgather(ws->tq.p, ws->fall.p, ps.M * sizeof(fr_t), st);
-        hipLaunchKernelGGL(recombine_kernel, dim3((uint32_t)((ps.M + 255) / 256)), dim3(256), 0, st, ws->fall.p, ps.G, (uint32_t)ps.M,
-                           ws->coef.p, ws->t.p);
+        {
+            const dim3 grid((uint32_t)((ps.M + 255) / 256)), block(256);
+            switch (ps.log_g) {
+                case 1: hipLaunchKernelGGL(recombine_kernel<1>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
+                case 2: hipLaunchKernelGGL(recombine_kernel<2>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
+                case 3: hipLaunchKernelGGL(recombine_kernel<3>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
+                default: hipLaunchKernelGGL(recombine_kernel<4>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
+            }
+        }
         HIP_CHECK(hipGetLastError());
     }
     poly_nonzero_check(ctx, ws->t.p, (uint32_t)(3 * n + 6), (uint32_t)n4, ws->flag.p);  // :506-511
