@@ -235,11 +235,21 @@ def main():
     for _ in range(args.warmup):
         proof = prover.prove([], circ.blinding)
     barrier()
+    if comm is not None:
+        comm.timing(True)   # event marks around this rank's all-gathers from here on
     t = time.perf_counter()
     for _ in range(args.steps):
         proof = prover.prove([], circ.blinding)
     barrier()
     dt = time.perf_counter() - t
+    exchange = None
+    if comm is not None:
+        calls, nbytes = comm.stats()
+        per_proof = args.steps + args.warmup
+        exchange = {"kind": comm.kind, "all_gathers_per_proof": calls // per_proof,
+                    "mib_contributed_per_proof": round(nbytes / per_proof / 2**20, 2),
+                    "stream_ms_per_proof_rank0": round(comm.timing(False) / args.steps, 3),
+                    "note": "time between event marks around each all-gather on rank 0's streams: the transfer and the wait for the slowest rank"}
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -319,6 +329,7 @@ def main():
                                           world, "on the device by RCCL" if comm.kind == "rccl" else "through the host (gloo)"),
                        "setup_seconds": round(setup_s, 1), "proof_sha256_16": digest,
                        **({"exchange_note": exchange_note} if exchange_note else {})},
+            **({"exchange": exchange} if exchange else {}),
             "ntt_gbps": round(ntt_rate / 1e9, 2), "ntt_ms_coset_2^%d" % log4: round(ntt_ms, 4),
             "msm_mpoints_per_s": round(n / msm_s / 1e6, 3), "msm_ms_2^%d" % k: round(msm_s * 1e3, 3),
             # dominant kernel of the proof: the MSM bucket accumulation (over half of the GPU time).  Its bound is the

@@ -196,6 +196,11 @@ int32_t plonk_comm_create_loopback(plonk_ctx* ctx, uint32_t rank, uint32_t world
 void plonk_comm_destroy(plonk_comm* comm);
 /* All-gathers issued through this handle and the bytes this rank contributed to them. */
 int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* bytes);
+/* Exchange timing (no counterpart in the single-process reference; a measurement aid for multi-GPU runs).
+ * Returns in `elapsed_ms` (nullable) the stream time this rank's all-gathers took since the previous call --
+ * the wait for the slowest peer included -- measured by an event pair around each of them while timing is on;
+ * then switches timing on (enable != 0) or off.  Call it with the proofs' streams drained (after plonk_sync). */
+int32_t plonk_comm_timing(plonk_comm* comm, int32_t enable, double* elapsed_ms);
 /* Prover::prove with the commitments sharded: `srs_slice` holds g1_powers[shard_lo, shard_lo + len)
  * (plonk_srs_from_tau_range or an upload of that slice) and the ranks' slices must tile the point
  * range in rank order (checked; PLONK_E_INVALID otherwise).  Every rank passes the same witness and

@@ -109,6 +109,7 @@ SIGNATURES = {
     "plonk_comm_create_loopback": (_i32, [_vp, _u32, _u32, _sz, C.POINTER(_vp)]),
     "plonk_comm_destroy": (None, [_vp]),
     "plonk_comm_stats": (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "plonk_comm_timing": (_i32, [_vp, _i32, C.POINTER(C.c_double)]),
     "plonk_prove_3wire_sharded": (_i32, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "plonk_prove_3wire_grouped": (_i32, [_vp, _vp, C.POINTER(ShardSlices), _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "plonk_g1_sum": (_i32, [_vp, _sz, _vp]),

@@ -430,6 +430,19 @@ int32_t plonk_comm_stats(const plonk_comm* comm, uint64_t* calls, uint64_t* byte
     return PLONK_OK;
 }
 
+int32_t plonk_comm_timing(plonk_comm* comm, int32_t enable, double* elapsed_ms) {
+    if (!comm) return PLONK_E_INVALID;
+    try {
+        (void)hipSetDevice(comm->ex->device);
+        const double ms = comm->ex->take_elapsed_ms();
+        if (elapsed_ms) *elapsed_ms = ms;
+        comm->ex->set_timing(enable != 0);
+        return PLONK_OK;
+    } catch (const std::exception&) {
+        return PLONK_E_HIP;
+    }
+}
+
 int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
                                   plonk_comm* comm, const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev,
                                   const plonk_fr* c_evals_dev, const plonk_fr* public_inputs, size_t n_public_inputs,

@@ -14,6 +14,43 @@
 
 namespace plonk {
 
+Exchange::~Exchange() {
+    for (auto& pair : ev)
+        for (auto& e : pair)
+            if (e) (void)hipEventDestroy(e);
+}
+
+void Exchange::retire_oldest() {
+    const int i = (head + RING - pending) % RING;
+    float ms = 0.f;
+    HIP_CHECK(hipEventSynchronize(ev[i][1]));
+    HIP_CHECK(hipEventElapsedTime(&ms, ev[i][0], ev[i][1]));
+    elapsed_ms += ms;
+    --pending;
+}
+
+void Exchange::mark_begin(hipStream_t stream) {
+    if (!timed) return;
+    if (pending == RING) retire_oldest();
+    for (auto& e : ev[head])
+        if (!e) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventRecord(ev[head][0], stream));
+}
+
+void Exchange::mark_end(hipStream_t stream) {
+    if (!timed) return;
+    HIP_CHECK(hipEventRecord(ev[head][1], stream));
+    head = (head + 1) % RING;
+    ++pending;
+}
+
+double Exchange::take_elapsed_ms() {
+    while (pending) retire_oldest();
+    const double ms = elapsed_ms;
+    elapsed_ms = 0.0;
+    return ms;
+}
+
 namespace {
 
 struct RcclApi {
@@ -65,7 +102,9 @@ struct RcclExchange : Exchange {
         }
     }
     void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
+        mark_begin(stream);
         rccl_check(rccl().AllGather(send_dev, recv_dev, nbytes, ncclUint8, comm, stream), "ncclAllGather");
+        mark_end(stream);
         ++calls;
         bytes += nbytes;
     }
@@ -79,10 +118,12 @@ struct CallbackExchange : Exchange {
     void allgather(const void* send_dev, void* recv_dev, size_t nbytes, hipStream_t stream) override {
         send.resize(nbytes);
         recv.resize(nbytes * world);
+        mark_begin(stream);
         HIP_CHECK(hipMemcpyAsync(send.data(), send_dev, nbytes, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (fn(user, send.data(), nbytes, recv.data()) != 0) throw Error(PLONK_E_INTERNAL, "all-gather callback failed");
         HIP_CHECK(hipMemcpyAsync(recv_dev, recv.data(), nbytes * world, hipMemcpyHostToDevice, stream));
+        mark_end(stream);
         HIP_CHECK(hipStreamSynchronize(stream));   // `recv` is reused by the next call
         ++calls;
         bytes += nbytes;

@@ -17,11 +17,27 @@ struct Exchange {
     uint32_t rank = 0, world = 1;
     int device = 0;
     uint64_t calls = 0, bytes = 0;   // all-gathers issued and bytes contributed by this rank
-    virtual ~Exchange() {}
+    virtual ~Exchange();
     // recv_dev[r * bytes .. (r + 1) * bytes) = send_dev[0 .. bytes) of rank r, for every rank r;
     // ordered on `stream` like a kernel launch.
     virtual void allgather(const void* send_dev, void* recv_dev, size_t bytes, hipStream_t stream) = 0;
     virtual const char* kind() const = 0;
+    // Optional timing: a pair of events around every all-gather on its stream; the time between them is what
+    // the exchange costs this rank, the wait for the slowest peer included.
+    void set_timing(bool on) { timed = on; }
+    double take_elapsed_ms();   // stream time of the all-gathers since the last call (their streams must have drained)
+
+  protected:
+    void mark_begin(hipStream_t stream);
+    void mark_end(hipStream_t stream);
+
+  private:
+    static constexpr int RING = 64;
+    bool timed = false;
+    hipEvent_t ev[RING][2] = {};
+    int head = 0, pending = 0;
+    double elapsed_ms = 0.0;
+    void retire_oldest();
 };
 
 constexpr size_t COMM_ID_BYTES = 128;   // ncclUniqueId

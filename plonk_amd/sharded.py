@@ -94,6 +94,15 @@ class Communicator:
             raise _lib.PlonkError(rc, "plonk_comm_stats")
         return calls.value, nbytes.value
 
+    def timing(self, enable):
+        """Stream time (ms) this rank's all-gathers took since the previous call, the wait for the slowest
+        peer included; then switches the event marks on or off.  Call with the context synchronised."""
+        ms = C.c_double()
+        rc = _lib.lib.plonk_comm_timing(self.h, 1 if enable else 0, C.byref(ms))
+        if rc != 0:
+            raise _lib.PlonkError(rc, "plonk_comm_timing")
+        return ms.value
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib.plonk_comm_destroy(self.h)

@@ -187,6 +187,7 @@ extern "C" {
                                       out: *mut *mut PlonkComm) -> i32;
     pub fn plonk_comm_destroy(comm: *mut PlonkComm);
     pub fn plonk_comm_stats(comm: *const PlonkComm, calls: *mut u64, bytes: *mut u64) -> i32;
+    pub fn plonk_comm_timing(comm: *mut PlonkComm, enable: i32, elapsed_ms: *mut f64) -> i32;
     pub fn plonk_prove_3wire_sharded(ctx: *mut PlonkCtx, pk: *const PlonkPk, srs_slice: *const PlonkSrs, shard_lo: usize,
                                      comm: *mut PlonkComm, a_evals_dev: *const PlonkFr, b_evals_dev: *const PlonkFr,
                                      c_evals_dev: *const PlonkFr, public_inputs: *const PlonkFr, n_public_inputs: usize,

@@ -278,6 +278,9 @@ def test_bench_starts_its_own_ranks():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["proof_sha256_16"] == one["config"]["proof_sha256_16"]
     assert two["steps"] == 2 and two["value"] > 0
+    ex = two["exchange"]   # event marks around the all-gathers: 9 MSM shares + coverage check + quotient slices per proof
+    assert ex["kind"] == "callback" and ex["all_gathers_per_proof"] == 11 and ex["stream_ms_per_proof_rank0"] > 0
+    assert "exchange" not in one
     # asking for more ranks than WORLD_SIZE provides is an error, not a silent one-rank run
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
