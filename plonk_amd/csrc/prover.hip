@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void class_gather_kernel(const fr_t* __restric
 // (G/2) log2 G + G products per k instead of G^2, in the 29-bit-limb form (the values are only regrouped: the
 // transform is linear).  Only the multiplied operand of a butterfly is reduced; an element grows by at most 3p
 // per stage.
-static constexpr uint32_t SHARD_MAX_RANKS = 16;
+static constexpr uint32_t SHARD_MAX_RANKS = 8;   // the GPUs of one node
 struct RecombineConsts {
     frx tw[SHARD_MAX_RANKS / 2];   // w_G^(-j), j < G/2
     frx scale[SHARD_MAX_RANKS];    // 7^(-M m) / G
@@ -730,8 +730,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
             switch (ps.log_g) {
                 case 1: hipLaunchKernelGGL(recombine_kernel<1>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
                 case 2: hipLaunchKernelGGL(recombine_kernel<2>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
-                case 3: hipLaunchKernelGGL(recombine_kernel<3>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
-                default: hipLaunchKernelGGL(recombine_kernel<4>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
+                default: hipLaunchKernelGGL(recombine_kernel<3>, grid, block, 0, st, ws->fall.p, (uint32_t)ps.M, ws->coef.p, ws->t.p); break;
             }
         }
         HIP_CHECK(hipGetLastError());

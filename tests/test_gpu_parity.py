@@ -92,7 +92,8 @@ def test_ntt_batched_and_strided(ctx):
         assert pa.fr_from_array(arr[b * n:(b + 1) * n]) == offt.coset_fft(vs[b], w, 7, n)
 
 
-@pytest.mark.parametrize("log_n,flags", [(16, 0), (17, 3), (18, 2), (20, 0), (20, 3)])
+# 21, 22: three sweeps, the first with its merged step-twiddle table (the C restatement needs 9 s at 2^22)
+@pytest.mark.parametrize("log_n,flags", [(16, 0), (17, 3), (18, 2), (20, 0), (20, 3), (21, 2), (22, 3)])
 def test_ntt_matches_c_restatement(ctx, log_n, flags):
     n = 1 << log_n
     rng = np.random.default_rng(log_n * 7 + flags)
@@ -129,6 +130,42 @@ def test_ntt_full_size_properties(ctx, log_n):
     fd = ctx.ntt(delta, 2)
     for k in (0, 3, n - 1):
         assert pa.fr_from_array(fd[k:k + 1]) == [7 * pow(w, k, R_MOD) % R_MOD]
+
+
+@pytest.mark.parametrize("log_n,flags", [(21, 2), (23, 3), (24, 2), (25, 2), (25, 3), (26, 0)])
+def test_ntt_random_positions_closed_form(ctx, log_n, flags):
+    """Three- and four-sweep sizes (merged step-twiddle tables, whole and partial): the transform of a vector
+    with 48 nonzero entries at random positions, compared at 96 random output positions with the defining sums
+    evaluated with Python integers.  Every sweep's digit of the inputs and of the outputs takes many values, so
+    a wrong table entry or index split shows up."""
+    import random
+    import plonk_amd as pa
+    n = 1 << log_n
+    rnd = random.Random(1000 * log_n + flags)
+    idx = sorted(rnd.sample(range(n), 48))
+    vals = _rand(log_n + flags, len(idx))
+    w = root_of_unity(n)
+    inverse, coset = flags & 1, flags & 2
+    dev = ctx.alloc(n * 32)
+    try:
+        sparse = np.zeros((n, 4), dtype=np.uint64)
+        sparse[idx] = pa.fr_to_array(vals)
+        ctx.upload(dev, sparse)
+        del sparse
+        ctx.ntt_dev(dev, log_n, flags)
+        n_inv, w_inv, g_inv = pow(n, -1, R_MOD), pow(w, -1, R_MOD), pow(7, -1, R_MOD)
+        for k in [0, n - 1] + [rnd.randrange(n) for _ in range(94)]:
+            got = pa.fr_from_array(ctx.download(C.c_void_p(dev.value + 32 * k), 32).reshape(1, 4))
+            if not inverse:   # fft.rs:23-32, :121-137: sum_i c_i (g w^k)^i
+                x = (7 if coset else 1) * pow(w, k, R_MOD) % R_MOD
+                exp = sum(v * pow(x, i, R_MOD) for i, v in zip(idx, vals)) % R_MOD
+            else:             # fft.rs:42-59, :140-157: g^-k / n * sum_i e_i w^(-ik)
+                exp = sum(v * pow(w_inv, i * k % n, R_MOD) for i, v in zip(idx, vals)) * n_inv % R_MOD
+                if coset:
+                    exp = exp * pow(g_inv, k, R_MOD) % R_MOD
+            assert got == [exp], (log_n, flags, k)
+    finally:
+        ctx.free(dev)
 
 
 def test_ntt_largest_size(ctx):
