@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds of the library on the GPU box: runs the given command with this build and with
+# A/B of two builds of the library on the GPU box: runs the given command with the library as built in the tree and with
 # .ab/libplonk_base.so.  usage: tools/ab_run.sh <command...>
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $REPO
