@@ -168,6 +168,37 @@ def test_ntt_random_positions_closed_form(ctx, log_n, flags):
         ctx.free(dev)
 
 
+def test_ntt_merged_tables_with_other_generators_and_batches(ctx):
+    """The three-sweep size 2^21 with coset generators other than 7 (each (size, direction, generator) has a
+    plan of its own, several cached side by side, the fifth replacing the first) and as a strided batch of
+    three vectors: a single nonzero coefficient c at index j transforms to c (g w^k)^j."""
+    import plonk_amd as pa
+    log_n = 21
+    n = 1 << log_n
+    w = root_of_unity(n)
+    stride = n + 64
+    dev = ctx.alloc(3 * stride * 32)
+    try:
+        for g in (5, 11, 13, 17, 19, 7, 5):
+            js = [3, n // 3 + 1, n - 2]
+            vals = _rand(g, 3)
+            host = np.zeros((3 * stride, 4), dtype=np.uint64)
+            for b in range(3):
+                host[b * stride + js[b]] = pa.fr_to_array([vals[b]])[0]
+            ctx.upload(dev, host)
+            ctx.ntt_dev(dev, log_n, 2, shift=g, batch=3, stride=stride)
+            for b in range(3):
+                for k in (0, 1, 77777, n - 1):
+                    got = pa.fr_from_array(ctx.download(C.c_void_p(dev.value + 32 * (b * stride + k)), 32).reshape(1, 4))
+                    x = g * pow(w, k, R_MOD) % R_MOD
+                    assert got == [vals[b] * pow(x, js[b], R_MOD) % R_MOD], (g, b, k)
+            ctx.ntt_dev(dev, log_n, 3, shift=g, batch=3, stride=stride)
+            back = ctx.download(dev, 3 * stride * 32).reshape(3 * stride, 4)
+            assert np.array_equal(back, host), g   # the gaps between the vectors of the batch included
+    finally:
+        ctx.free(dev)
+
+
 def test_ntt_largest_size(ctx):
     """2^27 points = the 8n domain of a 2^24-gate circuit, four sweeps, 4 GiB per vector (the header
     admits up to 2^28): known transforms of a sparse vector at a few positions, then the inverse
