@@ -129,6 +129,26 @@ int32_t plonk_commit_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* c
 int32_t plonk_msm(plonk_ctx* ctx, const plonk_g1* points_host, const plonk_fr* scalars_host, size_t n,
                   plonk_g1* out);
 
+/* ---- polynomial evaluation, division and KZG openings on the device: the seams of polynomial.rs and kzg.rs that
+ * rounds 4 and 5 of the prover (and any caller that opens a committed polynomial) go through.  Coefficient
+ * vectors are device-resident Montgomery Fr, low degree first; trailing zeros are allowed (the reference's
+ * Polynomial strips them, which changes no value here). ---- */
+/* Polynomial::evaluate (polynomial.rs:103-113): *y_out = sum coeffs[i] z^i; 0 for len == 0. */
+int32_t plonk_poly_eval_dev(plonk_ctx* ctx, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z, plonk_fr* y_out);
+/* Polynomial::div_by_linear (polynomial.rs:188-204): q_out_dev[0 .. len-1) = quotient of the division by (X - z),
+ * the remainder f(z) dropped as the reference's synthetic division drops it.  len < 2 writes nothing (the empty
+ * quotient).  q_out_dev must not overlap coeffs_dev. */
+int32_t plonk_div_by_linear_dev(plonk_ctx* ctx, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z,
+                                plonk_fr* q_out_dev);
+/* OpeningProof::create (kzg.rs:262-276): *y_out = f(z), *proof_out = commit((f - y) / (X - z)).  PLONK_E_INVALID when
+ * the quotient is longer than the SRS (the reference panics, kzg.rs:232-238). */
+int32_t plonk_open_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z,
+                       plonk_fr* y_out, plonk_g1* proof_out);
+/* BatchOpening::create (kzg.rs:322-341): evals_out[i] = f_i(z) and the opening at z of g = sum_i gamma^i f_i. */
+int32_t plonk_open_batch_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* const* polys_dev, const size_t* lens,
+                             size_t count, const plonk_fr* z, const plonk_fr* gamma, plonk_fr* evals_out,
+                             plonk_g1* proof_out);
+
 /* ---- proving key: replaces preprocess (plonk/preprocess.rs:104-186) and ProvingKey
  * (plonk/types.rs:12).  Inputs are the per-gate selector vectors (constraint.rs:385-393) and the
  * S_sigma evaluation vectors of Permutation::compute (permutation.rs:113-126), each n = 2^log_n
@@ -290,8 +310,13 @@ typedef struct plonk_vk {
  * the verifier's half of the SRS, g2_tau = g2_generator * tau. */
 int32_t plonk_g2_generator(plonk_g2* out);
 int32_t plonk_g2_mul(const plonk_g2* p, const plonk_fr* k, plonk_g2* out);
-/* pairing_check (curve.rs:408-412): *equal = [e(p1, q1) == e(p2, q2)]. */
+/* pairing_check (curve.rs:408-412): *equal = [e(p1, q1) == e(p2, q2)].  PLONK_E_INVALID for a point that is off its
+ * curve, has an unreduced coordinate or (G2) lies outside the order-r subgroup. */
 int32_t plonk_pairing_check(const plonk_g1* p1, const plonk_g2* q1, const plonk_g1* p2, const plonk_g2* q2, int32_t* equal);
+/* OpeningProof::verify (kzg.rs:282-303), host only: *accepted = [e([f]_1 - y [1]_1, [1]_2) == e(proof, [tau]_2 - z [1]_2)].
+ * PLONK_E_INVALID for points the reference's types cannot hold or unreduced scalars. */
+int32_t plonk_open_verify(const plonk_g1* commitment, const plonk_fr* z, const plonk_fr* y, const plonk_g1* proof,
+                          const plonk_g2* g2_tau, int32_t* accepted);
 /* The verification key of preprocess (preprocess.rs:130-178) from a device-resident proving key:
  * the eight commitments (computed on the device), n, omega, k1, k2. */
 int32_t plonk_vk_from_pk(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs, plonk_vk* out);

@@ -95,3 +95,55 @@ def msm(points_arr, scalars_arr):
         return None
     zi = pow(Z, Q_MOD - 2, Q_MOD)
     return (X * zi * zi % Q_MOD, Y * zi * zi % Q_MOD * zi % Q_MOD)
+
+
+class Engine:
+    """The transforms and the round-3 loop of oracle.protocol.prove / preprocess run in the C
+    restatement (ref_ntt = fft.rs:23-157, ref_quotient = prover.rs:400-457) so that the oracle reaches
+    2^18 .. 2^20 gates; everything else of the protocol stays in oracle/protocol.py.  Independent
+    transforms and ranges of the 4n-point loop run on `threads` host threads (the C calls release
+    the interpreter lock)."""
+
+    def __init__(self, threads=8):
+        self.threads = threads
+
+    def _map(self, fn, items):
+        if self.threads <= 1 or len(items) <= 1:
+            return [fn(x) for x in items]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.threads) as ex:
+            return list(ex.map(fn, items))
+
+    def from_evaluations(self, evals, domain):
+        """polynomial.rs:56-65 -> fft.rs:42-59 (normalised coefficients)."""
+        from .fft import strip
+        if len(evals) == 0:
+            return []
+        assert len(evals) == domain.n
+        return strip(fr_list(ntt(fr_array(evals), 1)))
+
+    def quotient_poly(self, n, pk, a, b, c, z, pi, alpha, beta, gamma):
+        """prover.rs:364-457 and :497-498: the 15 coset transforms over 4n points (shift 7), the fused
+        loop (one pow and one inverse per point), the inverse coset transform; returns the normalised
+        coefficients of t."""
+        from .fft import strip
+        from .protocol import poly_shift
+        n4 = 4 * n
+        polys = [a, b, c, z, poly_shift(z, pk.omega), pk.q_m, pk.q_l, pk.q_r, pk.q_o, pk.q_c,
+                 pk.s_sigma1, pk.s_sigma2, pk.s_sigma3, pk.l1, pi]
+        ext = np.zeros((15, n4, 4), dtype=np.uint64)
+
+        def coset(i):
+            if polys[i]:
+                ext[i, :len(polys[i])] = fr_array(polys[i])
+                ntt(ext[i], 2)
+
+        self._map(coset, list(range(15)))
+        parts = max(1, self.threads)
+        step = -(-n4 // parts)
+        ranges = [(f, min(step, n4 - f)) for f in range(0, n4, step)]
+        outs = self._map(lambda r: quotient(ext, n, alpha, beta, gamma, pk.k1, pk.k2, r[0], r[1]), ranges)
+        t = np.concatenate(outs)
+        del ext, outs
+        ntt(t, 3)
+        return strip(fr_list(t))

@@ -418,10 +418,13 @@ class ProvingKey:
     pass
 
 
-def preprocess(cs, srs, use_trapdoor=False):
-    """preprocess.rs:104-186.  Returns (pk, vk dict, permutation, domain)."""
+def preprocess(cs, srs, use_trapdoor=False, engine=None):
+    """preprocess.rs:104-186.  Returns (pk, vk dict, permutation, domain).
+    `engine` (oracle.cref.Engine) runs the transforms in the C restatement of fft.rs instead of
+    the Python one; the values are the same."""
     n = cs.n
     domain = Domain(n)
+    from_evaluations = engine.from_evaluations if engine is not None else globals()["from_evaluations"]
     q_m, q_l, q_r, q_o, q_c = [from_evaluations(s, domain) for s in cs.selectors()]
     perm = Permutation(cs, domain)
     s1 = from_evaluations(perm.s_sigma1_evals, domain)
@@ -446,7 +449,7 @@ PROOF_G1 = ("a_comm", "b_comm", "c_comm", "z_comm", "t_lo_comm", "t_mid_comm", "
 PROOF_FR = ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval")
 
 
-def public_input_poly(cs, domain, public_inputs):
+def public_input_poly(cs, domain, public_inputs, from_evaluations=from_evaluations):
     """prover.rs:840-857."""
     ev = [0] * cs.n
     for i, pos in enumerate(cs.public_input_positions):
@@ -485,10 +488,14 @@ def quotient_evals(n, pk, a, b, c, z, pi, alpha, beta, gamma):
     return t
 
 
-def prove(cs, pk, perm, domain, srs, public_inputs, blinding, use_trapdoor=False, trace=None):
+def prove(cs, pk, perm, domain, srs, public_inputs, blinding, use_trapdoor=False, trace=None, engine=None):
     """prover.rs:62-149 with the RNG draws (b1..b6 :189-194, b7..b9 :310-312, b10,b11 :537-538)
-    injected as `blinding[0..11]`.  Returns a dict of 9 affine G1 points and 6 Fr values."""
+    injected as `blinding[0..11]`.  Returns a dict of 9 affine G1 points and 6 Fr values.
+    `engine` (oracle.cref.Engine) runs the transforms (fft.rs) and the round-3 loop
+    (prover.rs:400-457) in their C restatement, for sizes the Python loops cannot reach; every
+    other step stays as written here."""
     n = pk.n
+    from_evaluations = engine.from_evaluations if engine is not None else globals()["from_evaluations"]
     omega, k1, k2 = pk.omega, pk.k1, pk.k2
     b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11 = [x % R_MOD for x in blinding]
     cm = lambda p: commit(p, srs, use_trapdoor)
@@ -524,9 +531,13 @@ def prove(cs, pk, perm, domain, srs, public_inputs, blinding, use_trapdoor=False
     alpha = tr.squeeze_challenge("alpha")
 
     # Round 3 — :339-574
-    pi_poly = public_input_poly(cs, domain, public_inputs)
-    t_coset = quotient_evals(n, pk, a, b, c, z, pi_poly, alpha, beta, gamma)
-    t = strip(Domain(4 * n).coset_ifft(t_coset, 7))  # :497-498
+    pi_poly = public_input_poly(cs, domain, public_inputs, from_evaluations)
+    if engine is None:
+        t_coset = quotient_evals(n, pk, a, b, c, z, pi_poly, alpha, beta, gamma)
+        t = strip(Domain(4 * n).coset_ifft(t_coset, 7))  # :497-498
+    else:
+        t_coset = None
+        t = engine.quotient_poly(n, pk, a, b, c, z, pi_poly, alpha, beta, gamma)
     assert len(t) <= 3 * n + 6, "t_poly degree exceeds paper bound"  # :506-511
     t_lo = [0] * (n + 1); t_mid = [0] * (n + 1); t_hi = [0] * (n + 6)
     for i, coeff in enumerate(t):  # :521-529

@@ -4,8 +4,8 @@ interface of the reference's `backend_new` crate.  All arithmetic runs in libplo
 """
 from .api import (Context, Domain, Srs, Commitment, ProvingKey, Prover, Proof, fft, ifft, coset_fft, coset_ifft,
                   msm, fr_to_array, fr_from_array, PlonkError, VerificationKey, Verifier, g2_generator, g2_mul,
-                  pairing_check)
+                  pairing_check, Polynomial, OpeningProof, BatchOpening)
 
 __all__ = ["Context", "Domain", "Srs", "Commitment", "ProvingKey", "Prover", "Proof", "fft", "ifft", "coset_fft",
            "coset_ifft", "msm", "fr_to_array", "fr_from_array", "PlonkError", "VerificationKey", "Verifier", "g2_generator",
-           "g2_mul", "pairing_check"]
+           "g2_mul", "pairing_check", "Polynomial", "OpeningProof", "BatchOpening"]

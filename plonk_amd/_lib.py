@@ -96,6 +96,10 @@ SIGNATURES = {
     "plonk_commit": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "plonk_commit_dev": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "plonk_msm": (_i32, [_vp, _vp, _vp, _sz, _vp]),
+    "plonk_poly_eval_dev": (_i32, [_vp, _vp, _sz, _vp, _vp]),
+    "plonk_div_by_linear_dev": (_i32, [_vp, _vp, _sz, _vp, _vp]),
+    "plonk_open_dev": (_i32, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "plonk_open_batch_dev": (_i32, [_vp, _vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp, _vp, _vp, _vp]),
     "plonk_pk_create": (_i32, [_vp, _u32] + [_vp] * 10 + [_vp, _sz, C.POINTER(_vp)]),
     "plonk_pk_free": (None, [_vp]),
     "plonk_pk_commitments": (_i32, [_vp, _vp, _vp, _vp]),
@@ -127,6 +131,7 @@ SIGNATURES = {
     "plonk_g2_generator": (_i32, [_vp]),
     "plonk_g2_mul": (_i32, [_vp, _vp, _vp]),
     "plonk_pairing_check": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "plonk_open_verify": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "plonk_vk_from_pk": (_i32, [_vp, _vp, _vp, _vp]),
     "plonk_verify_3wire": (_i32, [_vp, _vp, _sz, _vp, _vp, _vp, _sz, C.POINTER(_i32)]),
     "plonk_proof_to_json": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),

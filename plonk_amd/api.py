@@ -349,6 +349,113 @@ class Commitment:
         return Commitment(_g1_value(out))
 
 
+class Polynomial:
+    """polynomial.rs:13-287 for a coefficient vector resident on the device (low degree first): evaluate (:103-113)
+    and div_by_linear (:188-204) run on the GPU; the vector comes back to the host only on request."""
+
+    def __init__(self, coeffs, ctx=None):
+        self.ctx = ctx or default_context()
+        a = _as_limbs(coeffs) if len(coeffs) else np.zeros((0, 4), dtype=np.uint64)
+        self.len = a.shape[0]
+        self.dev = self.ctx.alloc(max(self.len, 1) * 32)
+        if self.len:
+            self.ctx.upload(self.dev, a)
+
+    @classmethod
+    def _adopt(cls, ctx, dev, length):
+        p = cls.__new__(cls)
+        p.ctx, p.dev, p.len = ctx, dev, length
+        return p
+
+    def coeffs(self):
+        """Normalised coefficient list (polynomial.rs:91-99)."""
+        if not self.len:
+            return []
+        return _strip(fr_from_array(self.ctx.download(self.dev, self.len * 32).reshape(-1, 4)))
+
+    def evaluate(self, z):
+        y = _lib.Fr()
+        t = _fr_struct(z)
+        self.ctx.check(lib.plonk_poly_eval_dev(self.ctx.h, self.dev, self.len, C.byref(t), C.byref(y)))
+        return _fr_value(y)
+
+    def div_by_linear(self, z):
+        qlen = max(self.len - 1, 0)
+        q = self.ctx.alloc(max(qlen, 1) * 32)
+        t = _fr_struct(z)
+        self.ctx.check(lib.plonk_div_by_linear_dev(self.ctx.h, self.dev, self.len, C.byref(t), q))
+        return Polynomial._adopt(self.ctx, q, qlen)
+
+    def close(self):
+        if getattr(self, "dev", None):
+            self.ctx.free(self.dev)
+            self.dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OpeningProof:
+    """kzg.rs:258-304."""
+
+    def __init__(self, point):
+        self.point = point
+
+    @staticmethod
+    def create(poly, z, srs):
+        """(y, proof) with y = f(z) and proof = [(f - y) / (X - z)]_1 (kzg.rs:262-276); `poly` a Polynomial."""
+        y, out = _lib.Fr(), _lib.G1()
+        t = _fr_struct(z)
+        srs.ctx.check(lib.plonk_open_dev(srs.ctx.h, srs.h, poly.dev, poly.len, C.byref(t), C.byref(y), C.byref(out)))
+        return _fr_value(y), OpeningProof(_g1_value(out))
+
+    @staticmethod
+    def verify(commitment, z, y, proof, g2_tau):
+        """kzg.rs:282-303 against [tau]_2 (a plonk_g2, e.g. from g2_mul(g2_generator(), tau))."""
+        ok = C.c_int32()
+        c, w = _g1_struct(commitment.point), _g1_struct(proof.point)
+        zz, yy = _fr_struct(z), _fr_struct(y)
+        rc = lib.plonk_open_verify(C.byref(c), C.byref(zz), C.byref(yy), C.byref(w), C.byref(g2_tau), C.byref(ok))
+        if rc != 0:
+            raise PlonkError(rc, "plonk_open_verify: invalid input")
+        return bool(ok.value)
+
+
+class BatchOpening:
+    """kzg.rs:310-379."""
+
+    def __init__(self, proof, evaluations):
+        self.proof, self.evaluations = proof, evaluations
+
+    @staticmethod
+    def create(polys, z, gamma, srs):
+        """kzg.rs:322-341: y_i = f_i(z) and one opening of sum_i gamma^i f_i at z."""
+        k = len(polys)
+        ptrs = (C.c_void_p * max(k, 1))(*[p.dev for p in polys])
+        lens = (C.c_size_t * max(k, 1))(*[p.len for p in polys])
+        ys = (_lib.Fr * max(k, 1))()
+        out = _lib.G1()
+        zz, gg = _fr_struct(z), _fr_struct(gamma)
+        srs.ctx.check(lib.plonk_open_batch_dev(srs.ctx.h, srs.h, ptrs, lens, k, C.byref(zz), C.byref(gg), ys, C.byref(out)))
+        return BatchOpening(OpeningProof(_g1_value(out)), [_fr_value(ys[i]) for i in range(k)])
+
+    def verify(self, commitments, z, gamma, g2_tau):
+        """kzg.rs:344-378: the combined commitment sum gamma^i [f_i]_1 (an MSM on the device) and combined evaluation,
+        then OpeningProof::verify."""
+        if len(commitments) != len(self.evaluations):
+            return False
+        gp, powers = 1, []
+        for _ in commitments:
+            powers.append(gp)
+            gp = gp * gamma % R_MOD
+        combined = Commitment(msm([c.point for c in commitments], powers))
+        y = sum(g * e for g, e in zip(powers, self.evaluations)) % R_MOD
+        return OpeningProof.verify(combined, z, y, self.proof, g2_tau)
+
+
 def msm_window_bits(n):
     return lib.plonk_msm_window_bits(n)
 

@@ -487,6 +487,50 @@ int32_t plonk_prove_3wire_grouped(plonk_ctx* ctx, const plonk_pk* pk, const plon
     API_END()
 }
 
+// ---- stand-alone polynomial / opening seam ----
+int32_t plonk_poly_eval_dev(plonk_ctx* ctx, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z, plonk_fr* y_out) {
+    if (!ctx || !y_out || (len && !coeffs_dev)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const host::fr_h y = poly_evaluate(C_, reinterpret_cast<const fr_t*>(coeffs_dev), len, fr_in(z, "evaluate: point"));
+    memcpy(y_out->l, y.l, 32);
+    API_END()
+}
+
+int32_t plonk_div_by_linear_dev(plonk_ctx* ctx, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z, plonk_fr* q_out_dev) {
+    if (!ctx || (len && !coeffs_dev) || (len > 1 && !q_out_dev)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    poly_div_by_linear(C_, reinterpret_cast<const fr_t*>(coeffs_dev), len, fr_in(z, "div_by_linear: point"),
+                       reinterpret_cast<fr_t*>(q_out_dev));
+    API_END()
+}
+
+int32_t plonk_open_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* coeffs_dev, size_t len, const plonk_fr* z,
+                       plonk_fr* y_out, plonk_g1* proof_out) {
+    if (!ctx || !srs || !y_out || !proof_out || (len && !coeffs_dev)) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(s->device == C_->device, "open: SRS lives on another device");
+    host::fr_h y;
+    g1_from_host(kzg_open(C_, s, reinterpret_cast<const fr_t*>(coeffs_dev), len, fr_in(z, "open: point"), &y), proof_out);
+    memcpy(y_out->l, y.l, 32);
+    API_END()
+}
+
+int32_t plonk_open_batch_dev(plonk_ctx* ctx, const plonk_srs* srs, const plonk_fr* const* polys_dev, const size_t* lens,
+                             size_t count, const plonk_fr* z, const plonk_fr* gamma, plonk_fr* evals_out, plonk_g1* proof_out) {
+    if (!ctx || !srs || !proof_out || (count && (!polys_dev || !lens || !evals_out))) return PLONK_E_INVALID;
+    API_BEGIN(ctx)
+    const Srs* s = reinterpret_cast<const Srs*>(srs);
+    PLONK_REQUIRE(s->device == C_->device, "open batch: SRS lives on another device");
+    std::vector<const fr_t*> ps(count);
+    for (size_t k = 0; k < count; ++k) ps[k] = reinterpret_cast<const fr_t*>(polys_dev[k]);
+    std::vector<host::fr_h> ys(count);
+    g1_from_host(kzg_open_batch(C_, s, ps.data(), lens, count, fr_in(z, "open batch: point"), fr_in(gamma, "open batch: gamma"),
+                                ys.data()), proof_out);
+    for (size_t k = 0; k < count; ++k) memcpy(evals_out[k].l, ys[k].l, 32);
+    API_END()
+}
+
 int32_t plonk_g1_sum(const plonk_g1* points, size_t n, plonk_g1* out) {
     if (!out || (n && !points)) return PLONK_E_INVALID;
     g1_from_host(g1_sum_affine(points, n), out);
@@ -629,9 +673,14 @@ static host::G2AffineH g2_from(const plonk_g2& p) {
     a.inf = p.infinity != 0;
     return a;
 }
+// What ark's G2Affine can hold after deserialisation: reduced coordinates, on the curve, and in the order-r subgroup
+// (the cofactor of G2 is large, so an arbitrary curve point is almost never in it): [r] Q = O.
 static bool g2_ok(const host::G2AffineH& a) {
-    return a.inf || (!host::Fq::geq_p(a.x.c0) && !host::Fq::geq_p(a.x.c1) && !host::Fq::geq_p(a.y.c0) &&
-                     !host::Fq::geq_p(a.y.c1) && host::g2_on_curve(a));
+    if (a.inf) return true;
+    if (host::Fq::geq_p(a.x.c0) || host::Fq::geq_p(a.x.c1) || host::Fq::geq_p(a.y.c0) || host::Fq::geq_p(a.y.c1) ||
+        !host::g2_on_curve(a))
+        return false;
+    return host::g2_in_subgroup(a);
 }
 static bool g1_ok(const plonk_g1& p, host::G1AffineH* out) {
     memcpy(out->x.l, p.x, 48);
@@ -663,6 +712,27 @@ int32_t plonk_pairing_check(const plonk_g1* p1, const plonk_g2* q1, const plonk_
     const host::G2AffineH c = g2_from(*q1), d = g2_from(*q2);
     if (!g1_ok(*p1, &a) || !g1_ok(*p2, &b) || !g2_ok(c) || !g2_ok(d)) return PLONK_E_INVALID;
     *equal = host::pairing_check(a, c, b, d) ? 1 : 0;
+    return PLONK_OK;
+}
+
+int32_t plonk_open_verify(const plonk_g1* commitment, const plonk_fr* z, const plonk_fr* y, const plonk_g1* proof,
+                          const plonk_g2* g2_tau, int32_t* accepted) {
+    if (!commitment || !z || !y || !proof || !g2_tau || !accepted) return PLONK_E_INVALID;
+    *accepted = 0;
+    host::G1AffineH c, w;
+    const host::G2AffineH t2 = g2_from(*g2_tau);
+    host::fr_h zz, yy;
+    memcpy(zz.l, z->l, 32);
+    memcpy(yy.l, y->l, 32);
+    if (!g1_ok(*commitment, &c) || !g1_ok(*proof, &w) || !g2_ok(t2) || host::Fr::geq_p(zz) || host::Fr::geq_p(yy))
+        return PLONK_E_INVALID;
+    // [f]_1 - y [1]_1 and [tau]_2 - z [1]_2 (kzg.rs:289-294)
+    const host::fr_h yc = host::Fr::from_mont(yy), zc = host::Fr::from_mont(zz);
+    const host::G1XyzzH yg = host::g1_mul_limbs(host::g1_from_affine(host::g1_generator()), yc.l, 4);
+    const host::G1AffineH lhs = host::g1_to_affine(host::g1_add(host::g1_from_affine(c), host::g1_neg(yg)));
+    const host::G2AffineH zg = host::g2_mul_limbs(host::g2_generator(), zc.l, 4);
+    const host::G2AffineH rhs = host::g2_add(t2, host::g2_neg(zg));
+    *accepted = host::pairing_check(lhs, host::g2_generator(), w, rhs) ? 1 : 0;   // kzg.rs:297-302
     return PLONK_OK;
 }
 

@@ -137,6 +137,15 @@ inline G2AffineH g2_mul_limbs(const G2AffineH& p, const uint64_t* e, int nl) {
     }
     return r;
 }
+inline G2AffineH g2_neg(const G2AffineH& p) {
+    if (p.inf) return p;
+    return G2AffineH{p.x, f2_neg(p.y), false};
+}
+// membership in the order-r subgroup: [r] Q = O, with r the modulus of Fr
+inline bool g2_in_subgroup(const G2AffineH& p) {
+    const uint64_t r[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    return g2_mul_limbs(p, r, 4).inf;
+}
 
 // ---- pairing ----
 inline Fq12 line_value(const Fq2& slope, const G2AffineH& r, const G1AffineH& p) {

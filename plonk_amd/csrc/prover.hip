@@ -5,6 +5,7 @@
 // stays in HBM from the witness upload to the last commitment; the host sees only commitments,
 // six evaluations and the transcript.
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -113,6 +114,8 @@ Pk* pk_create(Ctx* ctx, uint32_t log_n, const plonk_fr* const sel[5], const plon
               const fr_h& k2, const uint32_t* pi_pos, size_t n_pi_pos) {
     PLONK_REQUIRE(log_n >= 2 && log_n <= 26, "pk: domain size must be 2^2 .. 2^26");
     std::unique_ptr<Pk> pk(new Pk());
+    static std::atomic<uint64_t> next_id{1};
+    pk->id = next_id.fetch_add(1);
     const size_t n = (size_t)1 << log_n, n4 = 4 * n;
     pk->device = ctx->device;
     pk->log_n = log_n;
@@ -345,7 +348,7 @@ struct ProverWorkspace {
     DevBuf<fr_t> fall;       // [G][M] the F_q of all ranks
     DevBuf<fr_t> ext_slice;  // [9][M] the key's coset tables on the class
     DevBuf<RecombineConsts> coef;   // twiddles and scalings of the inverse DFT across the ranks
-    const Pk* slice_pk = nullptr;
+    uint64_t slice_pk_id = 0;   // Pk::id the tables above were gathered from (0 = none)
     uint32_t slice_g = 0, slice_q = 0;
 };
 
@@ -385,7 +388,8 @@ static void point_shard_tables(Ctx* ctx, ProverWorkspace* ws, const Pk* pk, cons
     ws->sl.ensure(6 * M);
     ws->tq.ensure(M);
     ws->fall.ensure(n4);
-    if (ws->slice_pk == pk && ws->slice_g == ps.G && ws->slice_q == ps.q && ws->ext_slice.n >= 9 * M) return;
+    if (ws->slice_pk_id == pk->id && ws->slice_g == ps.G && ws->slice_q == ps.q && ws->ext_slice.n >= 9 * M) return;
+    ws->slice_pk_id = 0;
     ws->ext_slice.ensure(9 * M);
     hipLaunchKernelGGL(class_gather_kernel, dim3((uint32_t)((M + 255) / 256), 9), dim3(256), 0, ctx->stream, pk->ext.p, n4,
                        ps.log_g, ps.q, (uint32_t)M, ws->ext_slice.p);
@@ -409,7 +413,7 @@ static void point_shard_tables(Ctx* ctx, ProverWorkspace* ws, const Pk* pk, cons
     ws->coef.ensure(1);
     HIP_CHECK(hipMemcpyAsync(ws->coef.p, &rc, sizeof(rc), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ws->slice_pk = pk;
+    ws->slice_pk_id = pk->id;
     ws->slice_g = ps.G;
     ws->slice_q = ps.q;
 }
@@ -569,6 +573,106 @@ host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev,
     HIP_CHECK(hipMemcpy(&f, ws->flag.p, 4, hipMemcpyDeviceToHost));
     PLONK_REQUIRE(f == 0, "commit: polynomial degree exceeds SRS max degree");
     return r;
+}
+
+// ---- the stand-alone polynomial / opening seam: Polynomial::evaluate (polynomial.rs:103-113),
+//      Polynomial::div_by_linear (:188-204), OpeningProof::create (kzg.rs:262-276) and BatchOpening::create
+//      (kzg.rs:322-341) on the kernels rounds 4 and 5 of the prover run ----
+host::fr_h poly_evaluate(Ctx* ctx, const fr_t* coeffs_dev, size_t len, const fr_h& z) {
+    if (len == 0) return Fr::zero();
+    PLONK_REQUIRE(len < ((size_t)1 << 31), "evaluate: polynomial too long");
+    ProverWorkspace* ws = prover_workspace(ctx);
+    ws->evals.ensure(8);
+    PowTab tab;
+    pow_tables(ctx, &z, 1, (uint32_t)len, ws->powtab, &tab);
+    EvalArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.coeffs[0] = coeffs_dev; ea.len[0] = (uint32_t)len; ea.lo[0] = tab.lo; ea.hi[0] = tab.hi;
+    poly_eval_batch(ctx, ea, 1, ws->evals.p, ws->partial);
+    fr_h y;
+    HIP_CHECK(hipMemcpyAsync(&y, ws->evals.p, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return y;
+}
+
+// q_out_dev[0 .. len-1) = the quotient of the division by (X - z); the remainder f(z) is dropped (polynomial.rs:188-204).
+void poly_div_by_linear(Ctx* ctx, const fr_t* coeffs_dev, size_t len, const fr_h& z, fr_t* q_out_dev) {
+    if (len < 2) return;   // a constant (or the zero polynomial) has the empty quotient
+    PLONK_REQUIRE(len < ((size_t)1 << 31), "div_by_linear: polynomial too long");
+    ProverWorkspace* ws = prover_workspace(ctx);
+    ws->tmp.ensure(len);
+    if (Fr::is_zero(z)) {
+        poly_div_linear(ctx, coeffs_dev, (uint32_t)len, z, z, PowTab{nullptr, nullptr}, PowTab{nullptr, nullptr}, ws->tmp.p, q_out_dev, ws->totals);
+        return;
+    }
+    const fr_h z_inv = Fr::inv(z);
+    const fr_h pts[2] = {z, z_inv};
+    PowTab tabs[2];
+    pow_tables(ctx, pts, 2, (uint32_t)len, ws->powtab, tabs);
+    poly_div_linear(ctx, coeffs_dev, (uint32_t)len, z, z_inv, tabs[0], tabs[1], ws->tmp.p, q_out_dev, ws->totals);
+}
+
+// (y, [q]_1) with y = f(z), q = (f - y) / (X - z): subtracting y from the constant term changes the remainder of
+// the division (to zero), not its quotient, so f itself is divided.
+host::G1AffineH kzg_open(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len, const fr_h& z, fr_h* y_out) {
+    *y_out = poly_evaluate(ctx, coeffs_dev, len, z);
+    if (len < 2) return commit_checked(ctx, srs, coeffs_dev, 0);
+    ProverWorkspace* ws = prover_workspace(ctx);
+    ws->wq.ensure(len);
+    poly_div_by_linear(ctx, coeffs_dev, len, z, ws->wq.p);
+    return commit_checked(ctx, srs, ws->wq.p, len - 1);
+}
+
+// evaluations y_i = f_i(z) and the opening of g = sum_i gamma^i f_i at z (kzg.rs:322-341)
+host::G1AffineH kzg_open_batch(Ctx* ctx, const Srs* srs, const fr_t* const* polys_dev, const size_t* lens, size_t count,
+                               const fr_h& z, const fr_h& gamma, fr_h* evals_out) {
+    ProverWorkspace* ws = prover_workspace(ctx);
+    size_t max_len = 0;
+    for (size_t k = 0; k < count; ++k) {
+        PLONK_REQUIRE(lens[k] < ((size_t)1 << 31), "open batch: polynomial too long");
+        PLONK_REQUIRE(lens[k] == 0 || polys_dev[k] != nullptr, "open batch: null polynomial");
+        max_len = std::max(max_len, lens[k]);
+    }
+    ws->evals.ensure(8);
+    if (max_len) {
+        PowTab tab;
+        pow_tables(ctx, &z, 1, (uint32_t)max_len, ws->powtab, &tab);
+        for (size_t base = 0; base < count; base += EVAL_MAX) {
+            const uint32_t m = (uint32_t)std::min<size_t>(EVAL_MAX, count - base);
+            EvalArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            for (uint32_t k = 0; k < m; ++k) {
+                ea.coeffs[k] = polys_dev[base + k]; ea.len[k] = (uint32_t)lens[base + k]; ea.lo[k] = tab.lo; ea.hi[k] = tab.hi;
+            }
+            poly_eval_batch(ctx, ea, m, ws->evals.p, ws->partial);
+            HIP_CHECK(hipMemcpyAsync(evals_out + base, ws->evals.p, m * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    } else {
+        for (size_t k = 0; k < count; ++k) evals_out[k] = Fr::zero();
+    }
+    // g = sum gamma^i f_i, at most LINCOMB_MAX - 1 new terms per pass on top of the running sum
+    ws->wnum.ensure(std::max<size_t>(max_len, 1));
+    fr_h gp = Fr::one();
+    bool have = false;
+    for (size_t base = 0; base < count || !have;) {
+        LincombArgs la;
+        memset(&la, 0, sizeof(la));
+        uint32_t k = 0;
+        if (have) {
+            la.p[k] = ws->wnum.p; la.len[k] = (uint32_t)max_len; la.s[k] = lincomb_scalar(Fr::one()); ++k;
+        }
+        while (base < count && k < LINCOMB_MAX) {
+            la.p[k] = polys_dev[base]; la.len[k] = (uint32_t)lens[base]; la.s[k] = lincomb_scalar(gp); ++k;
+            gp = Fr::mul(gp, gamma);
+            ++base;
+        }
+        la.count = k;
+        if (max_len) poly_lincomb(ctx, la, ws->wnum.p, (uint32_t)max_len);
+        have = true;
+    }
+    fr_h y;
+    return kzg_open(ctx, srs, ws->wnum.p, max_len, z, &y);
 }
 
 // The kernels that detect a zero denominator (round 2) or an over-long polynomial (rounds 3, 5) raise a flag and

@@ -10,6 +10,7 @@ namespace plonk {
 
 // ProvingKey of backend_new/src/plonk/types.rs:12, resident on one device.
 struct Pk {
+    uint64_t id = 0;      // unique per key for the life of the process (an address can be reused after plonk_pk_destroy)
     int device = 0;
     uint32_t log_n = 0;
     size_t n = 0;
@@ -45,6 +46,11 @@ host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev,
 void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, const plonk_fr* b_ev, const plonk_fr* c_ev,
                  bool evals_on_device, const plonk_fr* pub, size_t n_pub, const plonk_fr* blinding, plonk_proof* out,
                  const ShardInfo* shard = nullptr);
+host::fr_h poly_evaluate(Ctx* ctx, const fr_t* coeffs_dev, size_t len, const host::fr_h& z);
+void poly_div_by_linear(Ctx* ctx, const fr_t* coeffs_dev, size_t len, const host::fr_h& z, fr_t* q_out_dev);
+host::G1AffineH kzg_open(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len, const host::fr_h& z, host::fr_h* y_out);
+host::G1AffineH kzg_open_batch(Ctx* ctx, const Srs* srs, const fr_t* const* polys_dev, const size_t* lens, size_t count,
+                               const host::fr_h& z, const host::fr_h& gamma, host::fr_h* evals_out);
 host::G1AffineH g1_sum_affine(const plonk_g1* pts, size_t n);
 void proof_challenges(const plonk_proof* pr, const plonk_fr* pub, size_t n_pub, plonk_fr out[6]);
 

@@ -110,8 +110,8 @@ int verify_3wire(const plonk_vk* vk, const uint64_t* pi_positions, size_t n_posi
         if (pi_positions[i] >= n) return PLONK_E_INVALID;
     const host::G2AffineH g2_tau = g2_in(*g2_tau_in);
     if (!g2_tau.inf && (!fq_reduced(g2_tau.x.c0) || !fq_reduced(g2_tau.x.c1) || !fq_reduced(g2_tau.y.c0) ||
-                        !fq_reduced(g2_tau.y.c1) || !host::g2_on_curve(g2_tau)))
-        return PLONK_E_INVALID;
+                        !fq_reduced(g2_tau.y.c1) || !host::g2_on_curve(g2_tau) || !host::g2_in_subgroup(g2_tau)))
+        return PLONK_E_INVALID;   // ark's G2Affine cannot hold a point outside the order-r subgroup
     const G1AffineH &a_comm = C[0], &b_comm = C[1], &c_comm = C[2], &z_comm = C[3], &t_lo = C[4], &t_mid = C[5], &t_hi = C[6],
                     &w_zeta = C[7], &w_zeta_omega = C[8];
     const fr_h &a_bar = ev[0], &b_bar = ev[1], &c_bar = ev[2], &s1_bar = ev[3], &s2_bar = ev[4], &zw_bar = ev[5];
@@ -272,6 +272,7 @@ struct JsonReader {
     const char* p;
     const char* end;
     std::vector<std::pair<std::string, std::string>> leaves;
+    std::vector<std::string> objects;   // path of every object met, in order (a key given twice shows up twice)
     bool ok = true;
     void ws() {
         while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
@@ -308,6 +309,7 @@ struct JsonReader {
         ws();
         if (p >= end) return false;
         if (*p == '{') {
+            objects.push_back(path);
             ++p;
             ws();
             if (p < end && *p == '}') { ++p; return true; }
@@ -353,6 +355,18 @@ struct JsonReader {
             if (kv.first == path) return &kv.second;
         return nullptr;
     }
+    // how often a field the format knows was given: serde's derived Deserialize refuses a known field given twice
+    // ("duplicate field"); unknown fields it skips, however often they come
+    size_t count_leaf(const std::string& path) const {
+        size_t c = 0;
+        for (const auto& kv : leaves) c += kv.first == path;
+        return c;
+    }
+    size_t count_object(const std::string& path) const {
+        size_t c = 0;
+        for (const auto& o : objects) c += o == path;
+        return c;
+    }
 };
 
 bool unhex(const std::string& in, uint8_t* out, size_t n) {
@@ -376,7 +390,7 @@ bool unhex(const std::string& in, uint8_t* out, size_t n) {
 // What serde's Deserialize of CompactProof reads: `compressed` of every point (curve.rs:436-450)
 // and `full` of every scalar (field.rs:310-320); everything else is ignored.
 bool proof_from_json(const char* json, size_t len, plonk_proof* out) {
-    JsonReader rd{json, json + len, {}, true};
+    JsonReader rd{json, json + len, {}, {}, true};
     if (!rd.value("", 0)) return false;
     rd.ws();
     if (rd.p != rd.end) return false;
@@ -389,6 +403,12 @@ bool proof_from_json(const char* json, size_t len, plonk_proof* out) {
     plonk_g1* g[9] = {&pr.a_comm, &pr.b_comm, &pr.c_comm, &pr.z_comm, &pr.t_lo_comm, &pr.t_mid_comm, &pr.t_hi_comm,
                       &pr.w_zeta_comm, &pr.w_zeta_omega_comm};
     plonk_fr* f[6] = {&pr.a_eval, &pr.b_eval, &pr.c_eval, &pr.s_sigma1_eval, &pr.s_sigma2_eval, &pr.z_omega_eval};
+    for (const char* round : {"round1", "round2", "round3", "round4", "round5"})
+        if (rd.count_object(round) > 1) return false;
+    for (int k = 0; k < 9; ++k)
+        if (rd.count_object(g1_paths[k]) > 1 || rd.count_leaf(std::string(g1_paths[k]) + ".compressed") > 1) return false;
+    for (int k = 0; k < 6; ++k)
+        if (rd.count_object(fr_paths[k]) > 1 || rd.count_leaf(std::string(fr_paths[k]) + ".full") > 1) return false;
     for (int k = 0; k < 9; ++k) {
         const std::string* v = rd.find(std::string(g1_paths[k]) + ".compressed");
         uint8_t comp[48];

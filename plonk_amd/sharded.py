@@ -70,14 +70,16 @@ class Communicator:
         h = C.c_void_p()
         if kind == "rccl":
             ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-            if rank == 0:
-                rc = _lib.lib.plonk_comm_unique_id(ident)
-                if rc != 0:
-                    raise _lib.PlonkError(rc, "plonk_comm_unique_id failed (is RCCL installed?)")
-            box = [bytes(ident)]
+            rc = _lib.lib.plonk_comm_unique_id(ident) if rank == 0 else 0
+            # rank 0 always reaches the broadcast, with its status in front: a failure there (RCCL not loadable)
+            # is then raised by every rank together instead of leaving the others waiting in the collective
+            box = [(rc, bytes(ident))]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+            rc, blob = box[0]
+            if rc != 0:
+                raise _lib.PlonkError(rc, "plonk_comm_unique_id failed on rank 0 (is RCCL installed?)")
+            ident = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(blob)
             ctx.check(_lib.lib.plonk_comm_create_rccl(ctx.h, ident, rank, world, C.byref(h)))
         elif kind == "callback":
             self.host = HostAllGather(dist, rank, world)

@@ -163,6 +163,15 @@ extern "C" {
                             out: *mut PlonkG1) -> i32;
     pub fn plonk_msm(ctx: *mut PlonkCtx, points_host: *const PlonkG1, scalars_host: *const PlonkFr, n: usize,
                      out: *mut PlonkG1) -> i32;
+    pub fn plonk_poly_eval_dev(ctx: *mut PlonkCtx, coeffs_dev: *const PlonkFr, len: usize, z: *const PlonkFr,
+                               y_out: *mut PlonkFr) -> i32;
+    pub fn plonk_div_by_linear_dev(ctx: *mut PlonkCtx, coeffs_dev: *const PlonkFr, len: usize, z: *const PlonkFr,
+                                   q_out_dev: *mut PlonkFr) -> i32;
+    pub fn plonk_open_dev(ctx: *mut PlonkCtx, srs: *const PlonkSrs, coeffs_dev: *const PlonkFr, len: usize, z: *const PlonkFr,
+                          y_out: *mut PlonkFr, proof_out: *mut PlonkG1) -> i32;
+    pub fn plonk_open_batch_dev(ctx: *mut PlonkCtx, srs: *const PlonkSrs, polys_dev: *const *const PlonkFr, lens: *const usize,
+                                count: usize, z: *const PlonkFr, gamma: *const PlonkFr, evals_out: *mut PlonkFr,
+                                proof_out: *mut PlonkG1) -> i32;
     pub fn plonk_pk_create(ctx: *mut PlonkCtx, log_n: u32, q_m: *const PlonkFr, q_l: *const PlonkFr, q_r: *const PlonkFr,
                            q_o: *const PlonkFr, q_c: *const PlonkFr, s_sigma1: *const PlonkFr, s_sigma2: *const PlonkFr,
                            s_sigma3: *const PlonkFr, k1: *const PlonkFr, k2: *const PlonkFr, pi_positions: *const u32,
@@ -213,6 +222,8 @@ extern "C" {
     pub fn plonk_g2_mul(p: *const PlonkG2, k: *const PlonkFr, out: *mut PlonkG2) -> i32;
     pub fn plonk_pairing_check(p1: *const PlonkG1, q1: *const PlonkG2, p2: *const PlonkG1, q2: *const PlonkG2,
                                equal: *mut i32) -> i32;
+    pub fn plonk_open_verify(commitment: *const PlonkG1, z: *const PlonkFr, y: *const PlonkFr, proof: *const PlonkG1,
+                             g2_tau: *const PlonkG2, accepted: *mut i32) -> i32;
     pub fn plonk_vk_from_pk(ctx: *mut PlonkCtx, pk: *const PlonkPk, srs: *const PlonkSrs, out: *mut PlonkVk) -> i32;
     pub fn plonk_verify_3wire(vk: *const PlonkVk, public_input_positions: *const u64, n_positions: usize,
                               g2_tau: *const PlonkG2, proof: *const PlonkProof, public_inputs: *const PlonkFr,

@@ -11,6 +11,14 @@ from oracle import curve, protocol as P
 from oracle.field import R_MOD
 
 
+@pytest.fixture(autouse=True, params=["build_host", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+def where(request):
+    """Every test of this file runs twice: in the CPU-only run (`-m "not gpu"`, where the library was just
+    built) and in the GPU run (`-m gpu`, on the box that only received the prebuilt library), so the host-side
+    encoders, the JSON wire format and the verifier are exercised on both machines."""
+    return request.param
+
+
 def _declared():
     text = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)

@@ -300,3 +300,34 @@ def test_c_restatement_matches_python():
     t = cref.fr_list(cref.quotient(ext, 16, tr["alpha"], tr["beta"], tr["gamma"], pk.k1, pk.k2))
     assert t == tr["t_coset"]
     assert cref.fr_list(cref.quotient(ext, 16, tr["alpha"], tr["beta"], tr["gamma"], pk.k1, pk.k2, 5, 9)) == tr["t_coset"][5:14]
+
+
+def test_prover_with_the_c_engine_matches_the_python_oracle():
+    """oracle.cref.Engine (the transforms and the round-3 loop run by the C restatement, what generates the
+    2^18 / 2^20-gate fixtures) gives the proofs the all-Python oracle gave: the golden 2^6 / 2^10 bytes, and a
+    circuit with public inputs against a fresh Python run."""
+    class _S:
+        pass
+
+    gold = {e["name"]: e for e in golden("proofs.json")}
+    eng = cref.Engine(4)
+    for k in (6, 10):
+        cs, bl = P.synthetic_circuit(k)
+        srs = _S()
+        srs.tau, srs.max_degree, srs.g1_powers = P.synthetic_tau(k), cs.n + 10, [None] * (cs.n + 11)
+        pk, vk, perm, dom = P.preprocess(cs, srs, use_trapdoor=True, engine=eng)
+        tr = {}
+        proof = P.prove(cs, pk, perm, dom, srs, [], bl, use_trapdoor=True, trace=tr, engine=eng)
+        e = gold["synthetic_2^%d" % k]
+        assert P.proof_to_bytes(proof).hex() == e["proof"]
+        assert [curve.compress(vk[key]).hex() for key in ("q_m", "q_l", "q_r", "q_o", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")] == e["vk"]
+        assert ["%064x" % tr[key] for key in ("beta", "gamma", "alpha", "zeta", "v", "u")] == e["challenges"]
+    cs = P.range_proof_circuit(8, 42)
+    srs = _S()
+    srs.tau, srs.max_degree, srs.g1_powers = 424242, cs.n + 10, [None] * (cs.n + 11)
+    bl = list(range(3, 14))
+    pk, vk, perm, dom = P.preprocess(cs, srs, use_trapdoor=True)
+    want = P.prove(cs, pk, perm, dom, srs, [42], bl, use_trapdoor=True)
+    pk2, vk2, perm2, dom2 = P.preprocess(cs, srs, use_trapdoor=True, engine=eng)
+    assert vk2 == vk
+    assert P.prove(cs, pk2, perm2, dom2, srs, [42], bl, use_trapdoor=True, engine=eng) == want

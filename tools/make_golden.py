@@ -1,10 +1,15 @@
 """Generates tests/golden/*.json from the CPU oracle (oracle/).  The reference ships no golden
 vectors and cannot be run here, so these pin the oracle's own outputs: any later change to the
 oracle or the HIP path that alters a byte shows up against them.
-Usage: python tools/make_golden.py [--big]   (--big adds the 2^14 and 2^16 synthetic proofs)."""
+Usage: python tools/make_golden.py [--big] [--huge] [--only-huge]
+  --big   adds the 2^14 and 2^16 synthetic proofs (Python oracle throughout, about an hour);
+  --huge  adds 2^18 and 2^20 (the benchmark size): oracle/protocol.py with its transforms and its
+          round-3 loop run by the C restatement (oracle.cref.Engine), commitments as f(tau)*G;
+          minutes on 8 cores, ~6 GiB of memory;
+  --only-huge  leaves every other entry of proofs.json as it is."""
 import hashlib, json, os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import protocol as P, curve, fft as offt
+from oracle import protocol as P, curve, cref, fft as offt
 from oracle.field import R_MOD, root_of_unity, fr_to_bytes
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -58,11 +63,11 @@ class _TrapSrs:
         self.tau, self.max_degree, self.g1_powers = tau, max_degree, [None] * (max_degree + 1)
 
 
-def proof_case(name, cs, tau, blinding, pis):
+def proof_case(name, cs, tau, blinding, pis, engine=None):
     srs = _TrapSrs(tau, cs.n + 10)
-    pk, vk, perm, dom = P.preprocess(cs, srs, use_trapdoor=True)
+    pk, vk, perm, dom = P.preprocess(cs, srs, use_trapdoor=True, engine=engine)
     tr = {}
-    proof = P.prove(cs, pk, perm, dom, srs, pis, blinding, use_trapdoor=True, trace=tr)
+    proof = P.prove(cs, pk, perm, dom, srs, pis, blinding, use_trapdoor=True, trace=tr, engine=engine)
     assert P.verify(vk, srs, proof, pis)
     return {"name": name, "n": cs.n, "tau": hx(tau), "blinding": [hx(b) for b in blinding],
             "public_inputs": [hx(p) for p in pis], "proof": P.proof_to_bytes(proof).hex(),
@@ -70,26 +75,34 @@ def proof_case(name, cs, tau, blinding, pis):
             "challenges": [hx(tr[k]) for k in ("beta", "gamma", "alpha", "zeta", "v", "u")]}
 
 
-def proof_vectors(big):
+def proof_vectors(big, huge, only_huge):
     path = os.path.join(OUT, "proofs.json")
     old = {e["name"]: e for e in json.load(open(path))} if os.path.exists(path) else {}
-    tau = seeded(99, 1)[0]
-    bl = seeded(98, 11)
-    out = [proof_case("c1_square_add", P.square_add_circuit(), tau, bl, []),
-           proof_case("c2_range_proof_255", P.range_proof_circuit(8, 255), tau, bl, []),
-           proof_case("range_proof_42_pi", P.range_proof_circuit(8, 42), tau, bl, [42])]
-    ks = [6, 10] + ([14, 16] if big else [])
+    out = []
+    if not only_huge:
+        tau = seeded(99, 1)[0]
+        bl = seeded(98, 11)
+        out = [proof_case("c1_square_add", P.square_add_circuit(), tau, bl, []),
+               proof_case("c2_range_proof_255", P.range_proof_circuit(8, 255), tau, bl, []),
+               proof_case("range_proof_42_pi", P.range_proof_circuit(8, 42), tau, bl, [42])]
+    ks = ([] if only_huge else [6, 10] + ([14, 16] if big else [])) + (huge if huge else [])
     for k in ks:
         cs, blk = P.synthetic_circuit(k)
-        out.append(proof_case("synthetic_2^%d" % k, cs, P.synthetic_tau(k), blk, []))
+        engine = cref.Engine(os.cpu_count() or 1) if k >= 17 else None
+        out.append(proof_case("synthetic_2^%d" % k, cs, P.synthetic_tau(k), blk, [], engine))
         print("synthetic", k, "done", flush=True)
-    names = {e["name"] for e in out}
-    out += [e for n, e in old.items() if n not in names]  # keep earlier big cases
-    json.dump(out, open(path, "w"), indent=0)
+    fresh = {e["name"]: e for e in out}
+    merged = [fresh.pop(name, e) for name, e in old.items()]   # earlier cases keep their place (and their value unless regenerated)
+    merged += list(fresh.values())
+    merged.sort(key=lambda e: e["n"] if e["name"].startswith("synthetic") else 0)   # stable: named cases first, then by size
+    json.dump(merged, open(path, "w"), indent=0)
 
 
 if __name__ == "__main__":
-    ntt_vectors()
-    msm_vectors()
-    proof_vectors("--big" in sys.argv)
+    only_huge = "--only-huge" in sys.argv
+    if not only_huge:
+        ntt_vectors()
+        msm_vectors()
+    huge = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--huge=")] or ([18, 20] if "--huge" in sys.argv or only_huge else [])
+    proof_vectors("--big" in sys.argv, huge, only_huge)
     print("golden written to", OUT)
