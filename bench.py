@@ -34,31 +34,40 @@ def pmc_traffic(kernel, run_name):
 
 
 def cpu_baseline(log_n, srs_points):
-    """The C restatement of the reference's loops (oracle/cref) timed on the host cores over a bounded
-    sample of the prover's operation list -- 5 iNTT(m) + 16 NTT(4m) + quotient(4m) + 9 MSM(m) at
-    m = 2^16 (the reference prover's per-proof operations, prover.rs:181-837) -- first on one thread,
-    as backend_new runs, then with the same list spread over a pool of threads; both are scaled to
-    n = 2^log_n by the operation counts (N log N per transform, Pippenger's additions per MSM, linear
-    for the quotient loop).  `srs_points`: (m, 12) uint64 affine points (Montgomery x | y)."""
+    """The C restatement of the reference's loops (oracle/cref) timed on the host cores over the prover's
+    per-proof operation list -- 5 iNTT(n) + 16 NTT(4n) + quotient(4n) + 9 MSM(n) (prover.rs:181-837).
+    (i) All cores, at the full size n = 2^log_n: the list pulled from a queue by one thread per core, timed
+    directly (the stand-in for a rayon-parallel CPU prover).  (ii) One thread, as backend_new runs: a bounded
+    sample at m = 2^16 scaled to n by operation counts (N log N per transform, Pippenger's additions per MSM,
+    linear for the quotient loop) -- the full size on one thread would take minutes.
+    `srs_points`: (n, 12) uint64 affine points (Montgomery x | y)."""
     import math
     import queue
     import threading
     import numpy as np
     from oracle import cref
+    try:
+        cores = min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = min(16, os.cpu_count() or 1)
+
+    def op_list(lg, pts, quot_slices):
+        m = 1 << lg
+        rng = np.random.default_rng(1)
+        small = [rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64) for _ in range(5)]
+        big = [rng.integers(0, 1 << 62, size=(4 * m, 4), dtype=np.uint64) for _ in range(16)]
+        ext = np.stack(big[:15])
+        scal = [rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64) for _ in range(9)]
+        qs = 4 * m // quot_slices
+        return [("msm", (lambda s=s: cref.msm(pts, s))) for s in scal] + \
+               [("quot", (lambda i=i: cref.quotient(ext, m, 3, 5, 7, 6, 7, i * qs, qs))) for i in range(quot_slices)] + \
+               [("ntt4", (lambda a=a: cref.ntt(a, 2))) for a in big] + \
+               [("ntt1", (lambda a=a: cref.ntt(a, 1))) for a in small]
+
+    # (ii) one thread, bounded sample
     lm = min(log_n, 16)
     m = 1 << lm
-    rng = np.random.default_rng(1)
-    pts = np.ascontiguousarray(srs_points[:m])
-    small = [rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64) for _ in range(5)]
-    big = [rng.integers(0, 1 << 62, size=(4 * m, 4), dtype=np.uint64) for _ in range(16)]
-    ext = rng.integers(0, 1 << 62, size=(15, 4 * m, 4), dtype=np.uint64)
-    scal = [rng.integers(0, 1 << 62, size=(m, 4), dtype=np.uint64) for _ in range(9)]
-    # quotient: cut into 16 slices so that the pool can share it
-    qs = 4 * m // 16
-    ops = [("msm", (lambda s=s: cref.msm(pts, s))) for s in scal] + \
-          [("ntt4", (lambda a=a: cref.ntt(a, 2))) for a in big] + \
-          [("ntt1", (lambda a=a: cref.ntt(a, 1))) for a in small] + \
-          [("quot", (lambda i=i: cref.quotient(ext, m, 3, 5, 7, 6, 7, i * qs, qs))) for i in range(16)]
+    ops = op_list(lm, np.ascontiguousarray(srs_points[:m]), 16)
     per_class = {}
     t_all = time.perf_counter()
     for name, fn in ops:
@@ -66,12 +75,17 @@ def cpu_baseline(log_n, srs_points):
         fn()
         per_class[name] = per_class.get(name, 0.0) + time.perf_counter() - t
     serial_s = time.perf_counter() - t_all
-    try:
-        cores = min(16, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        cores = min(16, os.cpu_count() or 1)
+    n = 1 << log_n
+    c_of = lambda k: 3 if k < 32 else int(math.log(k)) + 2
+    msm_work = lambda k: k * math.ceil(255 / c_of(k)) + 2 * (1 << c_of(k)) * math.ceil(255 / c_of(k))
+    ntt_work = lambda lg: (1 << lg) * lg
+    total = (per_class["msm"] * msm_work(n) / msm_work(m) + per_class["ntt4"] * ntt_work(log_n + 2) / ntt_work(lm + 2) +
+             per_class["ntt1"] * ntt_work(log_n) / ntt_work(lm) + per_class["quot"] * n / m)
+
+    # (i) all cores, full size, timed directly (the longest operations first so the tail is short)
+    full_ops = op_list(log_n, np.ascontiguousarray(srs_points[:n]), 4 * cores)
     work = queue.Queue()
-    for item in ops:
+    for item in full_ops:
         work.put(item)
 
     def pull():
@@ -89,23 +103,14 @@ def cpu_baseline(log_n, srs_points):
     for x in th:
         x.join()
     threaded_s = time.perf_counter() - t
-    # scale the classes to n = 2^log_n
-    n = 1 << log_n
-    c_of = lambda k: 3 if k < 32 else int(math.log(k)) + 2
-    msm_work = lambda k: k * math.ceil(255 / c_of(k)) + 2 * (1 << c_of(k)) * math.ceil(255 / c_of(k))
-    ntt_work = lambda lg: (1 << lg) * lg
-    total = (per_class["msm"] * msm_work(n) / msm_work(m) + per_class["ntt4"] * ntt_work(log_n + 2) / ntt_work(lm + 2) +
-             per_class["ntt1"] * ntt_work(log_n) / ntt_work(lm) + per_class["quot"] * n / m)
-    speedup = serial_s / threaded_s
-    return {"value": round(total * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port", "extrapolated": True,
-            "sample": "oracle/cref (C restatement of backend_new fft.rs / prover.rs:415-457 / ark msm_bigint) over the per-proof "
-                      "operation list at m=2^%d on distinct SRS points: 9 MSM(m) %.2fs, 16 coset NTT(4m) %.2fs, 5 iNTT(m) %.2fs, "
-                      "quotient(4m) %.2fs on one thread; scaled to n=2^%d by operation counts" %
-                      (lm, per_class["msm"], per_class["ntt4"], per_class["ntt1"], per_class["quot"], log_n),
-            "sample_seconds": {"one_thread": round(serial_s, 2), "threads": round(threaded_s, 2)},
-            "all_cores": {"value": round(total / speedup * 1e3, 1), "unit": "ms", "cores": cores, "extrapolated": True,
-                          "how": "the same operation list pulled from a queue by %d threads ran %.2fx faster than on one; "
-                                 "that measured speed-up applied to the scaled one-thread figure" % (cores, speedup)},
+    return {"value": round(threaded_s * 1e3, 1), "unit": "ms", "cores": cores, "kind": "port", "extrapolated": False,
+            "sample": "oracle/cref (C restatement of backend_new fft.rs / prover.rs:415-457 / ark msm_bigint): the whole per-proof "
+                      "operation list at n=2^%d -- 9 MSM(n) on the SRS points, 16 coset NTT(4n), 5 iNTT(n), quotient(4n) in %d slices -- "
+                      "pulled from a queue by %d threads, timed directly" % (log_n, 4 * cores, cores),
+            "one_thread": {"value": round(total * 1e3, 1), "unit": "ms", "cores": 1, "extrapolated": True,
+                           "how": "the same list at m=2^%d on one thread (9 MSM %.2fs, 16 coset NTT(4m) %.2fs, 5 iNTT(m) %.2fs, "
+                                  "quotient(4m) %.2fs = %.2fs) scaled to n=2^%d by operation counts" %
+                                  (lm, per_class["msm"], per_class["ntt4"], per_class["ntt1"], per_class["quot"], serial_s, log_n)},
             "ntt_gbps": round(64.0 * 4 * m * 16 / per_class["ntt4"] / 1e9, 3),
             "msm_mpoints_per_s": round(9 * m / per_class["msm"] / 1e6, 4),
             "note": "the restatement is plain C, several times slower than tuned arkworks assembly would be: a stated baseline, not a target"}
@@ -256,6 +261,20 @@ def main():
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
     digest = __import__("hashlib").sha256(proof.to_bytes()).hexdigest()[:16]
+    # the same proof from host witness vectors (3 n 32 bytes of pageable memory cross PCIe inside the call), over
+    # the same number of steps: reported beside `value`, never as `value`
+    host_ms = None
+    if world == 1:
+        hp = pa.Prover(circ.wires, pk, srs, resident=False)
+        for _ in range(max(1, min(args.warmup, 2))):
+            hp.prove([], circ.blinding)
+        barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            hproof = hp.prove([], circ.blinding)
+        barrier()
+        host_ms = (time.perf_counter() - t) / args.steps * 1e3
+        assert hproof.to_bytes() == proof.to_bytes()
 
     # one more proof with the event marks on, on every rank (a sharded proof is a collective): the quotient kernel alone
     ctx.msm_set_timing(True)
@@ -316,6 +335,14 @@ def main():
         # products per point in quotient_kernel: x 1, gate 4, beta x / beta k x 3, beta sigma 3, the two triple products 6,
         # alpha 1, L1 term 2, 1/Z_H 1
         quot_muls = 21.0 * n4
+        # multiply-add slots: a mixed addition issues 3 542 v_mad_u64_u32 per lane (7 products of 2 x 196, two squarings of
+        # 105 + 196, one two-product reduction of 3 x 196), the kernel's first addition of a bucket (affine + affine) 2 366
+        mads = entries * 3542.0
+        # whole proof: what its kernels' field products would take at the measured product ceilings, with nothing else
+        # (no sort, no latency, no launch gaps) -- 9 MSM bucket passes and reductions (Fq), 4 iNTT(n) + 4 NTT(4n) +
+        # 1 iNTT(4n) butterflies, the quotient pass, the grand product (17 per gate) and the round 4-5 passes (~30 per gate)
+        floor_fq = 9.0 * fq_muls / fq_peak
+        floor_fr = (4.0 * (n // 2) * k + 5.0 * (n4 // 2) * log4 + quot_muls + 47.0 * n) / fr_peak
         out = {
             "metric": "prover_wall_time_ms_2^%d_gates" % k, "value": round(ms, 3), "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -341,7 +368,10 @@ def main():
                          "instruction_rate_bound": round(fq_instr_bound / 1e9, 2),
                          "frac_of_instruction_rate_bound": round(bucket_mul_rate / fq_instr_bound, 4),
                          "instruction_rate_bound_is": "v_mad_u64_u32 issue rate measured in this run (%.2f T lane-op/s) / 392 per product" % (mad_rate / 1e12),
-                         "work_per_launch": {"mixed_additions": entries, "fq_mul": bucket_muls},
+                         "mad_slot_frac": round(mads / (tm["bucket_ms"] * 1e-3) / mad_rate, 4),
+                         "mad_slot_frac_is": "v_mad_u64_u32 lane-operations the kernel must issue (3 542 per mixed addition x additions) / "
+                                             "launch time / the measured v_mad_u64_u32 issue rate: no model of a product's cost involved",
+                         "work_per_launch": {"mixed_additions": entries, "fq_mul": bucket_muls, "v_mad_u64_u32": mads},
                          "avg_launch_ms": round(tm["bucket_ms"], 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "hbm": {"bound": "hbm", "achieved": round(bucket_rate / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -368,17 +398,20 @@ def main():
                                   "hbm": {"bound": "hbm", "achieved": round(quot_bytes / (quot_ms * 1e-3) / 1e9, 2),
                                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(quot_bytes / (quot_ms * 1e-3) / HBM_PEAK, 4),
                                           "algorithmic_bytes_per_launch": quot_bytes}},
+            "roofline_proof": {"kernel": "whole proof (all kernels of one plonk_prove_3wire_dev call)", "bound": "valu",
+                               "achieved": round((floor_fq + floor_fr) * 1e3, 3), "peak": round(ms, 3), "unit": "ms",
+                               "frac": round((floor_fq + floor_fr) * 1e3 / ms, 4),
+                               "is": "time the proof's field products would take at the product ceilings measured in this run "
+                                     "(Fq %.2f ms: 9 x (bucket additions + bucket-set reduction); Fr %.2f ms: transforms, quotient, "
+                                     "rounds 2, 4, 5) over the measured time per proof" % (floor_fq * 1e3, floor_fr * 1e3)},
             "field_mul_peaks": {"fr_G_per_s": round(fr_peak / 1e9, 2), "fq_G_per_s": round(fq_peak / 1e9, 2),
                                 "v_mad_u64_u32_T_lane_op_per_s": round(mad_rate / 1e12, 2)},
         }
-        if world == 1:
-            # the same proof from host witness vectors (3 n 32 bytes over PCIe inside the call): never `value`
-            hp = pa.Prover(circ.wires, pk, srs, resident=False)
-            hp.prove([], circ.blinding)
-            t1 = time.perf_counter()
-            for _ in range(3):
-                hp.prove([], circ.blinding)
-            out["prover_ms_host_witness"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+        out["prover_ms_resident_witness"] = round(ms, 3)
+        out["value_is"] = ("plonk_prove_3wire_dev: witness vectors resident in HBM when the timed region starts, proof bytes on the host when "
+                           "it ends; prover_ms_host_witness is plonk_prove_3wire on the same input from pageable host memory, same step count")
+        if host_ms is not None:
+            out["prover_ms_host_witness"] = round(host_ms, 3)
         if not args.no_sweep:
             # stand-alone rates at the other sizes (forward NTT in place; commit of uniform scalars
             # against a resident SRS of the same size)
@@ -414,10 +447,10 @@ def main():
             out["ntt_gbps_by_size"] = ntt_sweep
             out["msm_mpoints_per_s_by_size"] = msm_sweep
         if not args.no_cpu_baseline and world == 1:
-            m = 1 << min(k, 16)
-            raw = (pa._lib.G1 * m)()
-            ctx.check(pa._lib.lib.plonk_srs_download(ctx.h, srs.h, 0, m, raw))
-            pts = np.frombuffer(raw, dtype=np.uint64).reshape(m, 13)[:, :12].copy()
+            raw = (pa._lib.G1 * n)()
+            ctx.check(pa._lib.lib.plonk_srs_download(ctx.h, srs.h, 0, n, raw))
+            pts = np.frombuffer(raw, dtype=np.uint64).reshape(n, 13)[:, :12].copy()
+            del raw
             out["cpu_baseline"] = cpu_baseline(k, pts)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -98,8 +98,12 @@ int32_t plonk_ntt(plonk_ctx* ctx, plonk_fr* data_host, uint32_t log_n, uint32_t 
  * static device array of 24.4 MiB that every GPU the library runs on holds until the process ends.
  * log_n above plonk_ntt_noalloc_max_log_n() (= 18) returns PLONK_E_INVALID.  The array keeps the
  * tables of the last (log_n, flags, shift); a call with another combination regenerates them with a
- * few kernels on the ctx stream.  All calls on one GPU share that GPU's array: calls that overlap
- * on one GPU (two contexts, two threads) race. */
+ * few kernels on the ctx stream.  All calls on one GPU share that GPU's array.  The library orders them:
+ * a host mutex per GPU, and each call's stream waits for an event recorded behind the previous call's last
+ * kernel (whatever context or thread made it), so successive calls from different contexts need no
+ * plonk_sync in between; they run one after the other on the device.  What stays the caller's duty: a
+ * captured graph replays against whatever tables the array holds at replay time, so no call with another
+ * (log_n, flags, shift) may run on that GPU between capture and the last replay. */
 int32_t plonk_ntt_dev_noalloc(plonk_ctx* ctx, plonk_fr* data_dev, uint32_t log_n, uint32_t flags,
                               const plonk_fr* shift);
 uint32_t plonk_ntt_noalloc_max_log_n(void);

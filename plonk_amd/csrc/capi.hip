@@ -79,6 +79,7 @@ int32_t plonk_ctx_create(int32_t device, plonk_ctx** out) {
     }
     try {
         ntt_noalloc_init(device);   // address of this device's static workspace (plonk_ntt_dev_noalloc)
+        ctx->c.ntt_lds_attr_set = true;   // ... which also raised the sweeps' LDS limit on this device
     } catch (const std::exception&) {
         delete ctx;
         return PLONK_E_HIP;

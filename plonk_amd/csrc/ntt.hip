@@ -18,6 +18,8 @@
 // depend on one digit only and ride on the tables of neighbouring sweeps.
 #include <algorithm>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "fieldx.cuh"
 
@@ -631,15 +633,29 @@ struct NoAllocState {
     unsigned char* ptr = nullptr;   // this device's address of `scratch`
     bool plan_valid = false;
     NttPlan plan;                   // tables inside the scratch array (arena stays empty)
+    // Calls on one GPU share the array whatever context (stream) or host thread they come from: the mutex
+    // serialises the host side, and every call's stream first waits for the event the previous call recorded
+    // behind its last kernel, so a call never reads tables that are still being written on another stream nor
+    // overwrites an image another stream is still transforming.
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    bool last_recorded = false;
 };
 static NoAllocState g_noalloc[NOALLOC_MAX_DEVICES];
+static std::mutex g_noalloc_init_mu;
 
 // Set-up, once per device with that device current (plonk_ctx_create calls it): the array's name is
 // a host-side stand-in; only the address looked up here may be handed to kernels.
 void ntt_noalloc_init(int device) {
     PLONK_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "ntt: device index out of range");
+    std::lock_guard<std::mutex> lock(g_noalloc_init_mu);
     NoAllocState& st = g_noalloc[device];
     if (st.ptr) return;
+    // the sweeps' dynamic-LDS limit is raised here, per device, so that the entry point itself makes no
+    // attribute call (a caller may have its stream under graph capture by then)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  112 * 1024));
+    HIP_CHECK(hipEventCreateWithFlags(&st.last, hipEventDisableTiming));
     void* p = nullptr;
     HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     st.ptr = static_cast<unsigned char*>(p);
@@ -662,6 +678,8 @@ void ntt_run_noalloc(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, c
     PLONK_REQUIRE(log_n <= NOALLOC_MAX_LOG_N, "ntt (no-alloc): size above the 2^18 elements the static workspace holds");
     NoAllocState& st = g_noalloc[ctx->device];
     PLONK_REQUIRE(st.ptr != nullptr, "ntt (no-alloc): static workspace of this device was not set up");
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (st.last_recorded) HIP_CHECK(hipStreamWaitEvent(ctx->stream, st.last, 0));   // behind the previous call, whatever its stream
     const bool same = st.plan_valid && st.plan.log_n == log_n && st.plan.flags == flags &&
                       (!(flags & NTT_COSET) || st.plan.shift == shift);
     if (!same) {
@@ -674,6 +692,8 @@ void ntt_run_noalloc(Ctx* ctx, fr_t* data_dev, uint32_t log_n, uint32_t flags, c
         st.plan_valid = true;
     }
     ntt_launch(ctx, ctx->stream, &st.plan, data_dev, 1, 0, reinterpret_cast<fr_t*>(st.ptr));
+    HIP_CHECK(hipEventRecord(st.last, ctx->stream));
+    st.last_recorded = true;
 }
 
 }  // namespace plonk

@@ -31,7 +31,7 @@ def _both(ctx, pa, log_n, flags, shift, seed):
 def test_noalloc_ntt_matches_ntt_dev(ctx):
     import plonk_amd as pa
     assert pa._lib.lib.plonk_ntt_noalloc_max_log_n() == 18
-    # (log_n, flags, shift): three sweeps, then a smaller two-sweep one, a single-sweep one, the
+    # (log_n, flags, shift): two sweeps, then a smaller two-sweep one, a single-sweep one, the
     # same plan twice in a row (tables reused), another generator, the largest size, sizes 1 and 2
     seq = [(17, 2, None), (13, 3, None), (9, 0, None), (9, 0, None), (13, 2, 5), (13, 3, 5), (18, 2, None), (18, 3, None),
            (16, 1, None), (11, 0, None), (1, 1, None), (0, 2, None), (12, 2, None)]
@@ -73,3 +73,38 @@ def test_noalloc_ntt_rejects_what_does_not_fit(ctx):
         assert pa._lib.lib.plonk_ntt_dev_noalloc(ctx.h, None, 4, 0, None) == pa._lib.PLONK_E_INVALID
     finally:
         ctx.free(dev)
+
+
+def test_noalloc_ntt_from_two_contexts_back_to_back(ctx):
+    """Two contexts (two streams) on the same GPU call one after the other with no synchronisation in between: the
+    second call's stream is ordered behind the first call's kernels by the library (the first call regenerates the
+    tables the second reads, and both use the one intermediate image)."""
+    import plonk_amd as pa
+    other = pa.Context(0)
+    log_n = 16
+    n = 1 << log_n
+    lib = pa._lib.lib
+    bufs = []
+    try:
+        for which, c in enumerate((ctx, other, ctx, other)):
+            a = np.random.default_rng(70 + which).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+            d = c.alloc(n * 32)
+            c.upload(d, a)
+            bufs.append((c, d, a))
+        # a first call with other tables, so that the sequence below starts by regenerating them
+        ctx.check(lib.plonk_ntt_dev_noalloc(ctx.h, bufs[0][1], 10, 0, None))
+        ctx.upload(bufs[0][1], bufs[0][2])
+        for c, d, _ in bufs:   # enqueued back to back, alternating streams, nothing waited for
+            c.check(lib.plonk_ntt_dev_noalloc(c.h, d, log_n, 2, None))
+        for c, d, a in bufs:
+            got = c.download(d, n * 32).reshape(n, 4)
+            ref = ctx.alloc(n * 32)
+            ctx.upload(ref, a)
+            ctx.check(lib.plonk_ntt_dev(ctx.h, ref, log_n, 2, None, 1, n))
+            want = ctx.download(ref, n * 32).reshape(n, 4)
+            ctx.free(ref)
+            assert np.array_equal(got, want)
+    finally:
+        for c, d, _ in bufs:
+            c.free(d)
+        other.close()
