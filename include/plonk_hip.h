@@ -354,7 +354,10 @@ int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_
  * dependency-chain-free kernel on this device (the integer-VALU ceiling the MSM and NTT are
  * priced against).  which: 0 = Fr, 1 = Fq in the 29-bit-limb lazy form the kernels multiply in;
  * 2 = Fr, 3 = Fq in the saturated 32-bit-limb form; 4 = the raw issue rate of v_mad_u64_u32 in
- * lane-operations per second (a 29-bit-limb Fr / Fq product is at least 162 / 392 of them). */
+ * lane-operations per second (a 29-bit-limb Fr / Fq product is at least 162 / 392 of them); 5 = Fq products
+ * with one Karatsuba level on the product half (a measured alternative the kernels do not use); 6 = Fq
+ * squarings; 7 = Fq products in the proportions of one mixed point addition (7 products, 2 squarings, one
+ * two-product reduction per 10), the ceiling that applies to the MSM's bucket accumulation. */
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second);
 /* HIP-event stopwatch on the ctx stream (the stream every kernel of this ctx runs on): start
  * records an event, stop records a second one, waits for it and returns the elapsed device
