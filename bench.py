@@ -24,13 +24,15 @@ def pmc_traffic(kernel, run_name):
     and WRITE_SIZE collected in separate runs and corrected as profiles/README.md states), with the
     file it came from; (None, None) when there is no measurement of this workload.  Not measured by
     this run: counters need the profiler."""
-    name = "r2_pmc_traffic.json"
-    try:
-        table = json.load(open(os.path.join(ROOT, "profiles", name)))
-        row = table[kernel]
-        return (row["hbm_bytes_per_launch"], "profiles/" + name) if row["run"] == run_name else (None, None)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # the newest round that measured this kernel
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", name)))
+            row = table[kernel]
+            if row["run"] == run_name:
+                return row["hbm_bytes_per_launch"], "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(log_n, srs_points):

@@ -826,8 +826,10 @@ static void msm_exchange(Ctx* ctx, MsmSlot& s, Exchange* ex, bool empty) {
 
 // Enqueue one MSM on slot `si`.  The scalars must be ready on ctx->stream (an event orders the sort
 // stream behind it).
+enum MsmPhase { PH_SORT = 1, PH_BUCKETS = 2, PH_TAIL = 4 };   // an MSM is enqueued phase by phase (sort and buckets usually together)
 static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts, const fr_t* scalars, size_t n,
-                        bool tail_phase, Exchange* ex) {
+                        uint32_t phases, Exchange* ex) {
+    const bool tail_phase = (phases & PH_TAIL) != 0;
     const g1x_affine_t* points = pts.px;
     // the shared bucket set is used unless the input is a sliver of the SRS (n < 2^(table_c - 12))
     const uint32_t shared = (pts.table_c && (n >> (pts.table_c > 12 ? pts.table_c - 12 : 0)) != 0) ? 1u : 0u;
@@ -901,7 +903,7 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
     const uint32_t bblk = (total_buckets + 255) / 256;
     uint32_t* n_big = s.bins.p + ORDER_BINS;
     hipStream_t st;
-    if (!tail_phase) {
+    if (phases & PH_SORT) {
     // ---- sort phase (the caller has ordered the sort stream behind the scalars) ----
     st = ws->sort_stream;
     s.timed = ws->timing;
@@ -929,6 +931,8 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
         HIP_CHECK(hipEventRecord(s.t_ev[1], st));
     }
     HIP_CHECK(hipEventRecord(s.sorted_ev, st));
+    }
+    if (phases & PH_BUCKETS) {
     // ---- bucket phase ----
     st = ws->bucket_stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.sorted_ev, 0));
@@ -974,8 +978,8 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
                        s.order.p, n_big, max_huge, s.pieces.p, s.buckets.p);
     if (s.timed) HIP_CHECK(hipEventRecord(s.t_ev[5], st));
     HIP_CHECK(hipEventRecord(s.buckets_ev, st));
-    return;
     }
+    if (!tail_phase) return;
     // ---- tail phase, on the ctx stream (idle while its commitments are in flight) ----
     st = ctx->stream;
     HIP_CHECK(hipStreamWaitEvent(st, s.buckets_ev, 0));
@@ -1061,7 +1065,7 @@ host::G1AffineH msm_run(Ctx* ctx, const MsmPoints& pts, const fr_t* scalars_dev,
 // Up to MSM_BATCH_MAX independent MSMs against the same points, pipelined on the device.  add() starts
 // one (its sort and bucket phases) as soon as its scalars are ready on ctx->stream, so the caller can
 // go on preparing the next scalars; finish() runs the reductions and collects the results.
-void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n) {
+void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n, bool hold_buckets) {
     PLONK_REQUIRE(b.count < MSM_BATCH_MAX, "msm: batch is full");
     PLONK_REQUIRE(n <= b.pts.level_stride, "msm: more scalars than points");
     MsmWorkspace* ws = msm_workspace(ctx);
@@ -1069,13 +1073,30 @@ void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n) {
     HIP_CHECK(hipStreamWaitEvent(ws->sort_stream, ws->ready, 0));
     b.scalars[b.count] = scalars_dev;
     b.n[b.count] = n;
-    msm_enqueue(ctx, ws, b.count, b.pts, scalars_dev, n, false, b.ex);
+    b.held[b.count] = hold_buckets;
+    msm_enqueue(ctx, ws, b.count, b.pts, scalars_dev, n, hold_buckets ? PH_SORT : (PH_SORT | PH_BUCKETS), b.ex);
     ++b.count;
+}
+
+// Starts the bucket kernels of the MSMs added with hold_buckets, behind what ctx->stream holds now.
+void msm_batch_release(Ctx* ctx, MsmBatch& b) {
+    MsmWorkspace* ws = msm_workspace(ctx);
+    bool any = false;
+    for (int k = 0; k < b.count; ++k) any = any || b.held[k];
+    if (!any) return;
+    HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));
+    HIP_CHECK(hipStreamWaitEvent(ws->bucket_stream, ws->ready, 0));
+    for (int k = 0; k < b.count; ++k) {
+        if (!b.held[k]) continue;
+        msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], PH_BUCKETS, b.ex);
+        b.held[k] = false;
+    }
 }
 
 void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFiller& filler) {
     MsmWorkspace* ws = msm_workspace(ctx);
-    for (int k = 0; k < b.count; ++k) msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], true, b.ex);
+    msm_batch_release(ctx, b);
+    for (int k = 0; k < b.count; ++k) msm_enqueue(ctx, ws, k, b.pts, b.scalars[k], b.n[k], PH_TAIL, b.ex);
     if (filler) {
         // behind what ctx->stream held when the last MSM was added (not behind the reductions above)
         if (b.count == 0) HIP_CHECK(hipEventRecord(ws->ready, ctx->stream));

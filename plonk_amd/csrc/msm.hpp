@@ -52,8 +52,12 @@ struct MsmBatch {
     Exchange* ex = nullptr;
     const fr_t* scalars[MSM_BATCH_MAX];
     size_t n[MSM_BATCH_MAX];
+    bool held[MSM_BATCH_MAX] = {false, false, false};
 };
-void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n);
+// hold_buckets: only the sort is started; the bucket kernels (which fill the chip and leave whatever is enqueued
+// beside them crawling) wait for msm_batch_release, or for msm_batch_finish.
+void msm_batch_add(Ctx* ctx, MsmBatch& b, const fr_t* scalars_dev, size_t n, bool hold_buckets = false);
+void msm_batch_release(Ctx* ctx, MsmBatch& b);
 void msm_batch_finish(Ctx* ctx, MsmBatch& b, host::G1AffineH* out, const MsmFiller& filler = nullptr);
 struct MsmTiming {
     float sort_ms, big_bucket_ms, bucket_ms, reduce_ms;

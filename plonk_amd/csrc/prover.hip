@@ -494,7 +494,7 @@ static host::G1AffineH commit_dev(Ctx* ctx, const Srs* srs, const fr_t* coeffs, 
 // commit_finish collects them.  Sharded runs all-gather the ranks' shares inside the MSM.
 // `batch`: how many commitments the round will add (it selects the placement, see ShardInfo).
 static void commit_add(Ctx* ctx, const Srs* srs, MsmBatch& b, const fr_t* coeffs, size_t len, uint32_t* flag_dev,
-                       const ShardInfo* shard, int batch) {
+                       const ShardInfo* shard, int batch, bool hold_buckets = false) {
     const CommitSlice cs = commit_slice(srs, shard, batch, b.count);
     if (b.count == 0) {
         b.pts = msm_points(cs.srs);
@@ -502,7 +502,7 @@ static void commit_add(Ctx* ctx, const Srs* srs, MsmBatch& b, const fr_t* coeffs
     }
     size_t lo, hi;
     commit_range(ctx, cs, coeffs, len, flag_dev, shard, &lo, &hi);
-    msm_batch_add(ctx, b, coeffs + lo, hi - lo);
+    msm_batch_add(ctx, b, coeffs + lo, hi - lo, hold_buckets);
 }
 
 static void commit_finish(Ctx* ctx, MsmBatch& b, const ShardInfo* shard, host::G1AffineH* out,
@@ -860,8 +860,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     // ---- round 4 (prover.rs:577-641) ----
     const fr_h zeta_omega = Fr::mul(zeta, pk->omega);
     // W_{zeta omega} = (z - z(zeta omega)) / (X - zeta omega) (:815-816) needs zeta alone -- the value
-    // subtracted from the constant term changes the remainder, not the quotient -- so its commitment
-    // is started here and runs underneath rounds 4 and 5; it enters the proof in the reference's order.
+    // subtracted from the constant term changes the remainder, not the quotient -- so its division and the
+    // sort of its commitment start here and run beside the evaluations of round 4.  Its bucket kernel is held
+    // back until round 5 has enqueued the division for W_zeta: a bucket kernel fills every wave slot of the
+    // chip, and the short dependent kernels of rounds 4-5 (evaluations, linear combination, division) would
+    // crawl beside it.  It enters the proof in the reference's order.
     MsmBatch openings;
     const fr_h zeta_inv = Fr::inv(zeta), zeta_omega_inv = Fr::inv(zeta_omega);
     PowTab tabs[4];   // zeta, 1/zeta, zeta omega, 1/(zeta omega)
@@ -871,7 +874,7 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     }
     HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
     poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->tmp.p, ws->wq2.p, ws->totals);
-    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2);
+    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2, /*hold_buckets=*/true);
     fr_h e6[6];
     {
         EvalArgs ea;
@@ -938,14 +941,11 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         la.count = k;
         const uint32_t wlen = (uint32_t)n + 6;
         poly_lincomb(ctx, la, ws->wnum.p, wlen);
-        // subtract the value at zeta (= r(zeta) + v a_bar + ... + v^5 s2_bar) from the constant term
-        EvalArgs ea;
-        memset(&ea, 0, sizeof(ea));
-        ea.coeffs[0] = ws->wnum.p; ea.len[0] = wlen; ea.lo[0] = tabs[0].lo; ea.hi[0] = tabs[0].hi;
-        poly_eval_batch(ctx, ea, 1, ws->evals.p + 6, ws->partial);
-        poly_poke_from(ctx, ws->wnum.p, 0, ws->evals.p + 6, true);   // the value stays on the device: nobody else needs it
+        // (r + v (a - a_bar) + ...) / (X - zeta) (:800-809): the constants subtracted from the numerator (r(zeta), v a_bar,
+        // ...) only change the remainder of the division, which is dropped -- the numerator is divided as it is
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
         poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
+        msm_batch_release(ctx, openings);   // W_{zeta omega}'s bucket kernel; W_zeta's sort runs beside it
         commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard, 2);
         host::G1AffineH w[2];
         commit_finish(ctx, openings, shard, w);

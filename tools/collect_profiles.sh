@@ -1,7 +1,7 @@
 #!/bin/bash
 # Condenses gpurun_out/prof_<tag>/ (written by tools/profile_round.sh) into the tracked profiles/<tag>_* files.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."
 P=gpurun_out/prof_$TAG
 cp $P/stats_bench/vm/*_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv

@@ -4,7 +4,7 @@
 # its own, the program directly after "--".  usage: tools/profile_round.sh <tag>   (e.g. r2)
 # Output under gpurun_out/prof_<tag>/; condense with tools/pmc_summary.py and copy into profiles/.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
