@@ -230,6 +230,11 @@ int32_t plonk_comm_timing(plonk_comm* comm, int32_t enable, double* elapsed_ms);
  * range in rank order (checked; PLONK_E_INVALID otherwise).  Every rank passes the same witness and
  * key and makes the same call; the ranks' shares of every MSM (the window sums of its reduction)
  * are all-gathered on the device and combined by every rank, so all ranks obtain the same proof. */
+/* A sharded proof is a sequence of collectives (eleven all-gathers): a rank whose call returns anything but PLONK_OK
+ * has left that sequence while its peers may already be queued in the next all-gather, so after a failed sharded
+ * call the plonk_comm of EVERY rank must be destroyed and a new one created before further proofs (failures
+ * that depend on the inputs all ranks share -- a polynomial longer than the SRS, an unsatisfied witness, slices
+ * that do not tile the point range -- are detected on every rank alike and leave the ranks in step). */
 int32_t plonk_prove_3wire_sharded(plonk_ctx* ctx, const plonk_pk* pk, const plonk_srs* srs_slice, size_t shard_lo,
                                   plonk_comm* comm, const plonk_fr* a_evals_dev, const plonk_fr* b_evals_dev,
                                   const plonk_fr* c_evals_dev, const plonk_fr* public_inputs, size_t n_public_inputs,
