@@ -304,3 +304,100 @@ def test_rust_shim_declares_exactly_the_header():
     # struct sizes the Rust side mirrors
     from plonk_amd import _lib
     assert C.sizeof(_lib.G2) == 200 and C.sizeof(_lib.Vk) == 8 + 8 * 104 + 3 * 32
+
+
+def test_json_reader_survives_mutated_input():
+    """plonk_proof_from_json on a few thousand mutations of a valid CompactProof text (bytes flipped, dropped,
+    doubled, truncated, keys duplicated): it returns PLONK_OK or PLONK_E_INVALID and never anything else, and
+    whatever it accepts serialises back to a valid 624-byte proof."""
+    import json
+    import random
+    import plonk_amd as pa
+    from conftest import golden
+    from plonk_amd import _lib
+    e = golden("proofs.json")[1]
+    text = pa.Proof.from_bytes(bytes.fromhex(e["proof"])).to_json().encode()
+    rng = random.Random(99)
+    accepted = 0
+    for trial in range(3000):
+        b = bytearray(text)
+        for _ in range(rng.choice([1, 1, 2, 5])):
+            kind = rng.randrange(5)
+            pos = rng.randrange(len(b)) if b else 0
+            if kind == 0 and b:
+                b[pos] = rng.randrange(256)
+            elif kind == 1 and b:
+                del b[pos:pos + rng.choice([1, 2, 17])]
+            elif kind == 2:
+                b[pos:pos] = b[pos:pos + rng.choice([1, 8, 64])]
+            elif kind == 3:
+                b = b[:pos]
+            elif b:
+                b[pos] = rng.choice(b'{}[]":,\\ \n')
+        raw = _lib.Proof()
+        rc = _lib.lib.plonk_proof_from_json(bytes(b), len(b), C.byref(raw))
+        assert rc in (_lib.PLONK_OK, _lib.PLONK_E_INVALID), (trial, rc)
+        if rc == _lib.PLONK_OK:
+            accepted += 1
+            assert len(pa.Proof(raw).to_bytes()) == 624
+    assert accepted < 3000     # most mutations are refused
+    # a known field given twice is refused (serde: "duplicate field"); an unknown field given twice is skipped
+    obj = json.loads(text)
+    dup_known = text.decode().replace('"round2":', '"round2":{"z":{"compressed":"0x00"}},"round2":', 1)
+    assert _lib.lib.plonk_proof_from_json(dup_known.encode(), len(dup_known), C.byref(_lib.Proof())) == _lib.PLONK_E_INVALID
+    inner = text.decode().replace('"compressed":', '"compressed":"0x11","compressed":', 1)
+    assert _lib.lib.plonk_proof_from_json(inner.encode(), len(inner), C.byref(_lib.Proof())) == _lib.PLONK_E_INVALID
+    unknown = text.decode().replace('"round1":', '"extra":1,"extra":2,"round1":', 1)
+    assert _lib.lib.plonk_proof_from_json(unknown.encode(), len(unknown), C.byref(_lib.Proof())) == _lib.PLONK_OK
+    assert obj["round1"]
+
+
+def test_g2_inputs_outside_the_subgroup_are_refused():
+    """plonk_pairing_check / plonk_g2_mul / plonk_verify_3wire take only what ark's G2Affine can hold: a point on the
+    twist curve y^2 = x^3 + 4 (1 + u) that is not in the order-r subgroup is an error, not a verdict."""
+    import plonk_amd as pa
+    from plonk_amd import _lib, api
+    from oracle import pairing
+    # a curve point with small x: solve y^2 = x^3 + 4(1+u) in Fq2; the cofactor is huge, so it is almost surely outside
+    q = curve.Q_MOD
+
+    def f2_mul(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+    def f2_pow(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = f2_mul(r, a)
+            a = f2_mul(a, a)
+            e >>= 1
+        return r
+
+    def f2_sqrt(a):   # q = 3 mod 4: candidate a^((q^2+7)/16)-style roots are awkward; use the (q^2 - 1)/2 test and Tonelli-free search
+        if f2_pow(a, (q * q - 1) // 2) != (1, 0):
+            return None
+        # a1 = a^((q-3)/4); x0 = a1 * a; alpha = a1 * x0  (Adj-Rodriguez for q = 3 mod 4)
+        a1 = f2_pow(a, (q - 3) // 4)
+        x0 = f2_mul(a1, a)
+        alpha = f2_mul(a1, x0)
+        if alpha == (q - 1, 0):
+            return f2_mul((0, 1), x0)
+        b = f2_pow(((1 + alpha[0]) % q, alpha[1]), (q - 1) // 2)
+        return f2_mul(b, x0)
+
+    x = (1, 0)
+    while True:
+        x3 = f2_mul(f2_mul(x, x), x)
+        rhs = ((x3[0] + 4) % q, (x3[1] + 4) % q)
+        y = f2_sqrt(rhs)
+        if y is not None and f2_mul(y, y) == rhs:
+            break
+        x = (x[0] + 1, 0)
+    off = api._g2_struct((x, y))
+    G, H = curve.G1_GEN, pa.g2_generator()
+    with pytest.raises(pa.PlonkError):
+        pa.pairing_check(G, off, G, H)
+    out = _lib.G2()
+    k = api._fr_struct(5)
+    assert _lib.lib.plonk_g2_mul(C.byref(off), C.byref(k), C.byref(out)) == _lib.PLONK_E_INVALID
+    assert pa.pairing_check(G, H, G, H)   # the generator itself passes the same check

@@ -13,9 +13,10 @@ circ = circuits.SyntheticCircuit(k)
 n = circ.n
 srs = pa.Srs.from_tau(circ.tau, n + 10)
 pk = pa.ProvingKey(n, circ.selectors, circ.sigmas, circ.k1, circ.k2, ())
-prover = pa.Prover(circ.wires, pk, srs, resident=True)
+host = len(sys.argv) > 3 and sys.argv[3] == "host"   # witness in (pageable) host memory: plonk_prove_3wire
+prover = pa.Prover(circ.wires, pk, srs, resident=not host)
 prover.prove([], circ.blinding)
 t = time.perf_counter()
 for _ in range(reps):
     prover.prove([], circ.blinding)
-print("prove 2^%d: %.3f ms" % (k, (time.perf_counter() - t) / reps * 1e3))
+print("prove 2^%d%s: %.3f ms" % (k, " (host witness)" if host else "", (time.perf_counter() - t) / reps * 1e3))
