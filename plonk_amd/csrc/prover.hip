@@ -699,7 +699,7 @@ static void check_flag(Ctx* ctx, ProverWorkspace* ws) {
 static void upload_staged(Ctx* ctx, ProverWorkspace* ws, fr_t* dst_dev, const void* src_host, size_t bytes, size_t stage_off) {
     constexpr size_t PIECE = (size_t)4 << 20;
     constexpr int THREADS = 4;
-    if (bytes < 2 * PIECE) {   // small vectors: the plain copy is as fast
+    if (bytes < 2 * PIECE || !ws->stage || stage_off + bytes > ws->stage_bytes) {   // small vectors: the plain copy is as fast; very large ones are not staged
         HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
         return;
     }
@@ -731,7 +731,8 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
     ws->scr.ensure(n); ws->tp.ensure(3 * ns);
     ws->wnum.ensure(ns); ws->wq.ensure(ns); ws->wq2.ensure(ns); ws->tmp.ensure(ns); ws->evals.ensure(8); ws->flag.ensure(4);
     hipStream_t st = ctx->stream;
-    if (!evals_on_device && ws->stage_bytes < 3 * n * sizeof(fr_t)) {
+    // (up to 2^21 gates: 192 MiB of pinned host memory; larger witnesses go through the plain pageable copy)
+    if (!evals_on_device && 3 * n * sizeof(fr_t) <= ((size_t)192 << 20) && ws->stage_bytes < 3 * n * sizeof(fr_t)) {
         // the previous call's copies out of the old area are complete: every call ends with a stream synchronisation
         if (ws->stage) (void)hipHostFree(ws->stage);
         ws->stage = nullptr;

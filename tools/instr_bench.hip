@@ -36,6 +36,17 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
                 if (OP == 11) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : "vcc");
                 if (OP == 12) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(w[i]), "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(b[i]), "v"(b[(i+1)&7]) : "vcc");
                 if (OP == 13) asm volatile("v_mad_i32_i24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 14) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(w[i]));
+                if (OP == 15) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 16) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]));
+                if (OP == 17) asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(a[i]));
+                if (OP == 18) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 19) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 20) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(a[i]));
+                if (OP == 21) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : "vcc");
+                if (OP == 22) asm volatile("v_mad_u64_u32 %0, vcc, %1, 8, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
+                if (OP == 23) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 24) asm volatile("v_ashrrev_i32 %0, 29, %0" : "+v"(a[i]));
             }
         }
     }
@@ -86,5 +97,16 @@ int main() {
     run<10>("v_add_u32", 1);
     run<11>("v_addc_co_u32", 1);
     run<12>("v_mad_u64_u32 + v_addc_co (pair)", 2);
+    run<14>("v_lshrrev_b64", 1);
+    run<15>("v_alignbit_b32", 1);
+    run<16>("v_and_b32 (literal)", 1);
+    run<17>("v_lshrrev_b32", 1);
+    run<18>("v_sub_u32", 1);
+    run<19>("v_and_or_b32", 1);
+    run<20>("v_bfe_u32", 1);
+    run<21>("v_cndmask_b32", 1);
+    run<22>("v_mad_u64_u32 (inline constant)", 1);
+    run<23>("v_lshl_add_u32", 1);
+    run<24>("v_ashrrev_i32", 1);
     return 0;
 }
