@@ -26,7 +26,8 @@ struct LazyMul {
     static __device__ __forceinline__ elem mul(const elem& a, const elem& b) { return x_mul<X>(a, b); }
 };
 
-// ---- variants measured against x_mul, not used by the kernels (the table in DESIGN.md says why) ----
+// ---- variants measured against x_mul and not used by the kernels: none of them beats it (one Karatsuba level saves
+// multiply-adds but pays more in the 64-bit additions that recombine the halves) ----
 // One Karatsuba level on the product half: the 14 x 14 limb product as three 7 x 7 products (147 multiply-adds
 // instead of 196), recombined with 64-bit column additions; the Montgomery reduction half is x_mul's.
 template <class X>

@@ -58,6 +58,8 @@ struct NttPassArgs {
     uint32_t is_last;
     uint64_t batch_stride;
     uint64_t in_len;              // first sweep: elements from this index on are taken as zero and not read (0 = all are read)
+    uint32_t tw_global;           // the sweep's own twiddles are read from sub_tw in memory (L2) instead of an LDS copy
+    uint32_t xcd_remap;           // narrow tiles: column-adjacent tiles are given to workgroups of one XCD (see the kernel)
 };
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -116,8 +118,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
         tw_mem.c = reinterpret_cast<uint32_t*>(base + 2 * half);
     }
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    for (uint32_t e = tid; e < (Np >> 1); e += NTT_THREADS) tw_mem.put(e, ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))));
+    // Workgroup ids go round the 8 XCDs, each with an L2 of its own.  A tile of one or two columns touches 32 or 64
+    // bytes of every 128-byte line it reads and writes; the tiles that share those lines are neighbours in tile
+    // order, so with narrow tiles four neighbouring tiles go to four consecutive workgroups of ONE XCD (ids 8
+    // apart), which run at about the same time: the line is then fetched, and written back, once per XCD instead
+    // of once per tile.  (The grid is a multiple of 32 workgroups whenever tiles are narrow.)
+    uint32_t tile = blockIdx.x;
+    if (p.xcd_remap) {
+        const uint32_t xcd = tile & 7u, slot = tile >> 3;
+        tile = ((slot >> 2) << 5) + (xcd << 2) + (slot & 3u);
+    }
+    const bool tw_global = p.tw_global != 0;
+    if (!tw_global)
+        for (uint32_t e = tid; e < (Np >> 1); e += NTT_THREADS) tw_mem.put(e, ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))));
+    auto tw = [&](uint32_t e) -> frx { return tw_global ? ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))) : tw_mem.get(e); };
     const fr_t* in = p.in + (size_t)blockIdx.y * p.batch_stride;
     fr_t* out = p.out + (size_t)blockIdx.y * p.batch_stride;
 
@@ -206,18 +220,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
                 // stages R-1 and R-2 of block 0: the only twiddle that is not 1 is w_4
                 const frx y0 = x_add_lazy<FrX>(x0, x2), y2 = x_sub_lazy<FrX, 3>(x0, x2);
                 const frx y1 = x_norm_u<FrX>(x_add_lazy<FrX>(x1, x3)), y3 = x_sub_lazy<FrX, 3>(x1, x3);
-                const frx t3 = x_mul<FrX>(y3, tw_mem.get(Np >> 2));
+                const frx t3 = x_mul<FrX>(y3, tw(Np >> 2));
                 z0 = x_add_lazy<FrX>(y0, y1);        // < 8p
                 z1 = x_sub_lazy<FrX, 5>(y0, y1);     // < 9p
                 z2 = x_add_lazy<FrX>(y2, t3);
                 z3 = x_sub_lazy<FrX, 3>(y2, t3);
             } else {
                 const uint32_t ea = brev(blk, R - s) << (s - 2);
-                const frx ts = tw_mem.get(2 * ea);
+                const frx ts = tw(2 * ea);
                 const frx t2 = x_mul<FrX>(x2, ts), t3 = x_mul<FrX>(x3, ts);
                 const frx y0 = x_add_lazy<FrX>(x0, t2), y2 = x_sub_lazy<FrX, 3>(x0, t2);
                 const frx y1 = x_add_lazy<FrX>(x1, t3), y3 = x_sub_lazy<FrX, 3>(x1, t3);
-                const frx u1 = x_mul<FrX>(y1, tw_mem.get(ea)), u3 = x_mul<FrX>(y3, tw_mem.get(ea + (Np >> 2)));
+                const frx u1 = x_mul<FrX>(y1, tw(ea)), u3 = x_mul<FrX>(y3, tw(ea + (Np >> 2)));
                 z0 = x_add_lazy<FrX>(y0, u1);
                 z1 = x_sub_lazy<FrX, 3>(y0, u1);
                 z2 = x_add_lazy<FrX>(y2, u3);
@@ -345,16 +359,17 @@ Ctx::~Ctx() {
 static void plan_geometry(NttPlan* pl, uint32_t log_n, uint32_t flags) {
     pl->log_n = log_n;
     pl->flags = flags;
-    // One sweep up to the tile size; two up to 2^20 (tiles of at least two 32-byte columns); from there
-    // sweeps of 2^8, the last ones shortened -- by two stages at a time where possible: a sweep of an
-    // even number of stages runs them all in pairs, and the first pair of a sweep costs one product
-    // per four elements instead of four (measured on MI355X, coset transform: 2^22 as 8+8+6 0.605 ms,
-    // as 8+7+7 0.627 ms, as 11+11 -- single-column tiles, 32-byte accesses -- 0.756 ms).
+    // One sweep up to the tile size; two up to 2^21; from there sweeps of 2^8, the last ones shortened -- by
+    // two stages at a time where possible: a sweep of an even number of stages runs them all in pairs, and
+    // the first pair of a sweep costs one product per four elements instead of four (measured on MI355X,
+    // coset transform: 2^22 as 8+8+6 0.56 ms, as 8+7+7 0.627 ms, as 11+11 -- single-column tiles, with the
+    // neighbouring tiles kept on one XCD and the twiddles read from L2 -- 0.59 ms; 2^21 as 11+10 0.275 ms
+    // against 0.284 ms in three sweeps).
     uint32_t P;
     if (log_n <= NTT_TILE_LOG) {
         P = 1;
         pl->R[0] = log_n;
-    } else if (log_n <= 2 * NTT_TILE_LOG - 2) {
+    } else if (log_n <= 2 * NTT_TILE_LOG - 1) {
         P = 2;
         pl->R[0] = (log_n + 1) / 2;
         pl->R[1] = log_n / 2;
@@ -581,7 +596,11 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         a.log_c = log_c;
         const uint32_t tiles = 1u << (log_n - R - log_c);
         const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
-        const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + ((size_t)1 << R) / 2 * 36 + 16;
+        // an LDS copy of the sweep's twiddles (2^(R-1) entries of 36 bytes) beside a full tile leaves room for one
+        // workgroup per CU from R = 9 on; those sweeps read their twiddles from the 48 KiB table in L2 instead
+        a.tw_global = R >= 9 ? 1u : 0u;
+        a.xcd_remap = (log_c < 2 && tiles >= 32) ? 1u : 0u;
+        const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + (a.tw_global ? 0 : ((size_t)1 << R) / 2 * 36) + 16;
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, a);
         HIP_CHECK(hipGetLastError());
         log_h += R;

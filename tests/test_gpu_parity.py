@@ -92,7 +92,8 @@ def test_ntt_batched_and_strided(ctx):
         assert pa.fr_from_array(arr[b * n:(b + 1) * n]) == offt.coset_fft(vs[b], w, 7, n)
 
 
-# 21, 22: three sweeps, the first with its merged step-twiddle table (the C restatement needs 9 s at 2^22)
+# 21: two sweeps of 11 and 10 stages (single-column tiles, twiddles from L2); 22: three sweeps, the first with its merged
+# step-twiddle table (the C restatement needs 9 s at 2^22)
 @pytest.mark.parametrize("log_n,flags", [(16, 0), (17, 3), (18, 2), (20, 0), (20, 3), (21, 2), (22, 3)])
 def test_ntt_matches_c_restatement(ctx, log_n, flags):
     n = 1 << log_n
@@ -132,9 +133,10 @@ def test_ntt_full_size_properties(ctx, log_n):
         assert pa.fr_from_array(fd[k:k + 1]) == [7 * pow(w, k, R_MOD) % R_MOD]
 
 
-@pytest.mark.parametrize("log_n,flags", [(21, 2), (23, 3), (24, 2), (25, 2), (25, 3), (26, 0)])
+@pytest.mark.parametrize("log_n,flags", [(21, 2), (21, 3), (22, 2), (23, 3), (24, 2), (25, 2), (25, 3), (26, 0)])
 def test_ntt_random_positions_closed_form(ctx, log_n, flags):
-    """Three- and four-sweep sizes (merged step-twiddle tables, whole and partial): the transform of a vector
+    """The largest two-sweep size (2^21: sweeps of 11 and 10 stages over single-column tiles) and three- and four-sweep
+    sizes (merged step-twiddle tables, whole and partial): the transform of a vector
     with 48 nonzero entries at random positions, compared at 96 random output positions with the defining sums
     evaluated with Python integers.  Every sweep's digit of the inputs and of the outputs takes many values, so
     a wrong table entry or index split shows up."""
@@ -169,11 +171,11 @@ def test_ntt_random_positions_closed_form(ctx, log_n, flags):
 
 
 def test_ntt_merged_tables_with_other_generators_and_batches(ctx):
-    """The three-sweep size 2^21 with coset generators other than 7 (each (size, direction, generator) has a
+    """The three-sweep size 2^22 with coset generators other than 7 (each (size, direction, generator) has a
     plan of its own, several cached side by side, the fifth replacing the first) and as a strided batch of
     three vectors: a single nonzero coefficient c at index j transforms to c (g w^k)^j."""
     import plonk_amd as pa
-    log_n = 21
+    log_n = 22
     n = 1 << log_n
     w = root_of_unity(n)
     stride = n + 64
