@@ -130,9 +130,14 @@ __global__ __launch_bounds__(256) void field_mul_bench_kernel(typename M::elem* 
     x[4 * i] = a0; x[4 * i + 1] = a1; x[4 * i + 2] = a2; x[4 * i + 3] = a3;
 }
 
+// `lds_bytes` of dynamic LDS per workgroup (unused by the kernel) bound the workgroups a CU holds: 80 KiB leaves two
+// waves per SIMD, 160 KiB one -- the product rate at the occupancy of a register-heavy kernel.
 template <class M>
-static double run_bench(Ctx* ctx) {
+static double run_bench(Ctx* ctx, size_t lds_bytes = 0) {
     typedef typename M::elem elem;
+    if (lds_bytes)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(field_mul_bench_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_bytes));
     const int blocks = 256 * 8, threads = 256, iters = 256;
     const size_t n = (size_t)blocks * threads * 4;
     DevBuf<elem> buf(n);
@@ -147,11 +152,11 @@ static double run_bench(Ctx* ctx) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, 8);
+    hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), lds_bytes, ctx->stream, buf.p, 8);
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), 0, ctx->stream, buf.p, iters);
+        hipLaunchKernelGGL(field_mul_bench_kernel<M>, dim3(blocks), dim3(threads), lds_bytes, ctx->stream, buf.p, iters);
         HIP_CHECK(hipEventRecord(e1, ctx->stream));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -248,6 +253,10 @@ double bench_field_mul(Ctx* ctx, uint32_t which) {
         case 6: return run_bench<LazySqr<FqX>>(ctx);
         case 7: return run_madd_mix<FqX>(ctx);
 
+        case 8: return run_bench<LazyMul<FqX>>(ctx, 80 * 1024);    // two waves per SIMD
+        case 9: return run_bench<LazyMul<FqX>>(ctx, 160 * 1024);   // one
+        case 10: return run_bench<LazyMul<FrX>>(ctx, 80 * 1024);
+        case 11: return run_bench<LazyMul<FrX>>(ctx, 160 * 1024);
         case 4: return run_mad_rate(ctx);
         case 0: return run_bench<LazyMul<FrX>>(ctx);
         case 1: return run_bench<LazyMul<FqX>>(ctx);

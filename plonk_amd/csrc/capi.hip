@@ -817,7 +817,7 @@ int32_t plonk_synthetic_circuit(uint32_t log_n, plonk_fr* a, plonk_fr* b, plonk_
 }
 
 int32_t plonk_bench_field_mul(plonk_ctx* ctx, uint32_t which, double* muls_per_second) {
-    if (!ctx || !muls_per_second || which > 7) return PLONK_E_INVALID;
+    if (!ctx || !muls_per_second || which > 11) return PLONK_E_INVALID;
     API_BEGIN(ctx)
     *muls_per_second = bench_field_mul(C_, which);
     API_END()

@@ -55,10 +55,8 @@ struct NttPassArgs {
     uint32_t log_n, R, log_s, log_c, log_h;
     uint32_t n_prev;              // number of earlier sweeps
     uint32_t r_prev[NTT_MAX_PASSES];
-    uint32_t is_last;
     uint64_t batch_stride;
     uint64_t in_len;              // first sweep: elements from this index on are taken as zero and not read (0 = all are read)
-    uint32_t tw_global;           // the sweep's own twiddles are read from sub_tw in memory (L2) instead of an LDS copy
     uint32_t xcd_remap;           // narrow tiles: column-adjacent tiles are given to workgroups of one XCD (see the kernel)
 };
 
@@ -95,6 +93,9 @@ struct LdsTile {
     }
 };
 
+// TWG: the sweep's own twiddles are read from sub_tw in memory (L2) instead of an LDS copy.  LAST: the last sweep
+// of a transform (rows contiguous in memory, output in natural order).
+template <bool TWG, bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const uint32_t R = p.R, log_c = p.log_c;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
     const uint32_t T = Np << log_c;
     // last sweep: rows are contiguous in memory -> image [c][d] with one element of padding per
     // row; other sweeps: image [d][c].
-    const bool rowmajor = p.is_last != 0;
+    constexpr bool rowmajor = LAST;
     const uint32_t plane = rowmajor ? (C * (Np + 1)) : T;
     LdsTile tile_mem;
     tile_mem.a = lds;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
         const uint32_t xcd = tile & 7u, slot = tile >> 3;
         tile = ((slot >> 2) << 5) + (xcd << 2) + (slot & 3u);
     }
-    const bool tw_global = p.tw_global != 0;
+    constexpr bool tw_global = TWG;
     if (!tw_global)
         for (uint32_t e = tid; e < (Np >> 1); e += NTT_THREADS) tw_mem.put(e, ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))));
     auto tw = [&](uint32_t e) -> frx { return tw_global ? ld_tw(p.sub_tw + ((size_t)e << (NTT_SUBTW_LOG - R))) : tw_mem.get(e); };
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
 
     // ---- tile geometry ----
     uint32_t hi = 0, lo_base = 0, k1_base = 0, rest = 0, log_h_rest = 0;
-    if (!p.is_last) {
+    if (!LAST) {
         const uint32_t tiles_per_hi_log = p.log_s - log_c;
         hi = tile >> tiles_per_hi_log;
         lo_base = (tile & ((1u << tiles_per_hi_log) - 1u)) << log_c;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
         frx x = tile_mem.get(lds_index(brev(k, R), c));
         if (p.post) x = x_mul<FrX>(x, ld_tw(p.post + k));
         size_t addr;
-        if (p.is_last) {
+        if (LAST) {
             const uint32_t hi_c = ((k1_base + c) << log_h_rest) + rest;
             const uint32_t K = digits_rev(hi_c, p.log_h, p.n_prev, p.r_prev);
             addr = (size_t)K + ((size_t)k << p.log_h);
@@ -544,6 +545,13 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
     return get_plan_shift(ctx, log_n, flags, host::Fr::from_u64(7));
 }
 
+// a tile and its twiddles take more than the 64 KiB of dynamic LDS a kernel may use by default (per device)
+static void ntt_raise_lds_limit() {
+    const void* variants[4] = {reinterpret_cast<const void*>(ntt_pass_kernel<false, false>), reinterpret_cast<const void*>(ntt_pass_kernel<false, true>),
+                               reinterpret_cast<const void*>(ntt_pass_kernel<true, false>), reinterpret_cast<const void*>(ntt_pass_kernel<true, true>)};
+    for (const void* f : variants) HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+}
+
 // `tmp`: the intermediate image of a multi-sweep transform (as large as the strided batch); unused
 // when the plan has one sweep.
 static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* data, uint32_t batch, size_t batch_stride,
@@ -551,8 +559,7 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
     const uint32_t log_n = pl->log_n, P = pl->n_pass;
     if (log_n == 0) return;  // fft.rs:64-66: n == 1 is the identity (1/n = 1 and k^0 = 1 too)
     if (!ctx->ntt_lds_attr_set) {   // per device, and a context belongs to one device
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+        ntt_raise_lds_limit();
         ctx->ntt_lds_attr_set = true;
     }
     uint32_t log_h = 0;
@@ -587,7 +594,6 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         a.log_h = log_h;
         a.n_prev = p;
         for (uint32_t q = 0; q < p; ++q) a.r_prev[q] = pl->R[q];
-        a.is_last = last ? 1u : 0u;
         a.batch_stride = batch_stride;
         a.in_len = (p == 0 && in_len < ((size_t)1 << log_n)) ? in_len : 0;
         uint32_t log_c = NTT_TILE_LOG > R ? NTT_TILE_LOG - R : 0;
@@ -598,10 +604,17 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         const size_t elems = last ? ((size_t)(1u << log_c) * ((1u << R) + 1)) : ((size_t)1 << (R + log_c));
         // an LDS copy of the sweep's twiddles (2^(R-1) entries of 36 bytes) beside a full tile leaves room for one
         // workgroup per CU from R = 9 on; those sweeps read their twiddles from the 48 KiB table in L2 instead
-        a.tw_global = R >= 9 ? 1u : 0u;
+        const bool tw_global = R >= 9;
         a.xcd_remap = (log_c < 2 && tiles >= 32) ? 1u : 0u;
-        const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + (a.tw_global ? 0 : ((size_t)1 << R) / 2 * 36) + 16;
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, batch), dim3(NTT_THREADS), lds_bytes, stream, a);
+        const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + (tw_global ? 0 : ((size_t)1 << R) / 2 * 36) + 16;
+        const dim3 grid(tiles, batch), block(NTT_THREADS);
+        if (tw_global) {
+            if (last) hipLaunchKernelGGL((ntt_pass_kernel<true, true>), grid, block, lds_bytes, stream, a);
+            else hipLaunchKernelGGL((ntt_pass_kernel<true, false>), grid, block, lds_bytes, stream, a);
+        } else {
+            if (last) hipLaunchKernelGGL((ntt_pass_kernel<false, true>), grid, block, lds_bytes, stream, a);
+            else hipLaunchKernelGGL((ntt_pass_kernel<false, false>), grid, block, lds_bytes, stream, a);
+        }
         HIP_CHECK(hipGetLastError());
         log_h += R;
     }
@@ -672,8 +685,7 @@ void ntt_noalloc_init(int device) {
     if (st.ptr) return;
     // the sweeps' dynamic-LDS limit is raised here, per device, so that the entry point itself makes no
     // attribute call (a caller may have its stream under graph capture by then)
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  112 * 1024));
+    ntt_raise_lds_limit();
     HIP_CHECK(hipEventCreateWithFlags(&st.last, hipEventDisableTiming));
     void* p = nullptr;
     HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
