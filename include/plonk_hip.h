@@ -230,7 +230,7 @@ int32_t plonk_comm_timing(plonk_comm* comm, int32_t enable, double* elapsed_ms);
  * range in rank order (checked; PLONK_E_INVALID otherwise).  Every rank passes the same witness and
  * key and makes the same call; the ranks' shares of every MSM (the window sums of its reduction)
  * are all-gathered on the device and combined by every rank, so all ranks obtain the same proof. */
-/* A sharded proof is a sequence of collectives (eleven all-gathers): a rank whose call returns anything but PLONK_OK
+/* A sharded proof is a sequence of collectives (thirteen all-gathers with two or more ranks): a rank whose call returns anything but PLONK_OK
  * has left that sequence while its peers may already be queued in the next all-gather, so after a failed sharded
  * call the plonk_comm of EVERY rank must be destroyed and a new one created before further proofs (failures
  * that depend on the inputs all ranks share -- a polynomial longer than the SRS, an unsatisfied witness, slices

@@ -479,7 +479,7 @@ void perm_grand_product(Ctx* ctx, const PermArgs& args, fr_t* z_out, fr_t* local
     HIP_CHECK(hipGetLastError());
 }
 
-// ---- polynomial evaluation: out[q] = sum_i coeffs_q[i] * x_q^i (prover.rs:595-604; polynomial.rs:103-113).
+// ---- polynomial evaluation: out[q] = sum_i coeffs_q[i] * x_q^(first_q + i) (prover.rs:595-604; polynomial.rs:103-113).
 //      A lane takes the 8 coefficients base + t + 256 k: Horner in x^256, then one product with x^(base + t)
 //      from the point's table; the lanes' terms are added up over the workgroup, the workgroups' by a second kernel. ----
 __global__ __launch_bounds__(256) void eval_partial_kernel(EvalArgs a, fr_t* __restrict__ partial, uint32_t blocks_per_poly) {
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void eval_partial_kernel(EvalArgs a, fr_t* __r
             h = fr_mul(h, step);
             if (i < len) h = fr_add(h, ld(a.coeffs[q] + i));
         }
-        h = fr_mul(h, tab_pow(a.lo[q], a.hi[q], first));
+        h = fr_mul(h, tab_pow(a.lo[q], a.hi[q], first + a.first[q]));
     }
     st(&red[tid], h);
     __syncthreads();

@@ -343,6 +343,7 @@ struct ProverWorkspace {
     DevBuf<fr_t> powtab;  // power tables of zeta, 1/zeta, zeta omega, 1/(zeta omega) for rounds 4-5
     DevBuf<uint32_t> flag;
     DevBuf<uint64_t> xchg;   // sharded proving: (lo, count) of every rank's SRS slice
+    DevBuf<fr_t> gath;       // sharded proving: the ranks' partial sums of rounds 4 and 5
     // round 3 sharded by evaluation point (see fold_kernel): this rank's residue class of the 4n coset
     DevBuf<fr_t> sl;         // [6][M] a b c z, z on the class of i + 4, pi: folded coefficients, then evaluations
     DevBuf<fr_t> tq;         // [M]    t on the class, then F_q
@@ -552,6 +553,7 @@ static void shard_check_coverage(Ctx* ctx, ProverWorkspace* ws, const Srs* srs, 
         next += all[REC * r + 1];
     }
     shard->global_end = next;
+    shard->slices = all;
     for (uint32_t g = 0; g < 2; ++g) {
         const uint32_t b = g + 2;
         uint32_t have = 0;
@@ -568,6 +570,61 @@ static void shard_check_coverage(Ctx* ctx, ProverWorkspace* ws, const Srs* srs, 
             PLONK_REQUIRE(at == next, "prove: the group slices of the ranks of one commitment do not cover the point range");
         }
     }
+}
+
+// ---- rounds 4-5 of a proof shared by several ranks, by coefficient range.  The evaluations at zeta are sums over the
+//      ranks' SRS slices of partial sums sum_{i in slice} c_i zeta^i.  An opening quotient q = N / (X - z) is only needed
+//      where this rank commits it, q_i = sum_{j > i} N_j z^(j - i - 1) for i in its slice [lo, hi) of that commitment: the
+//      terms with j < hi come from the rank's own coefficients of N, the rest is z^(hi - i - 1) T with
+//      T = z^(-hi) sum_{j >= hi} N_j z^j -- partial evaluations of N again, over the slices above.  Dividing the
+//      polynomial (N_lo, ..., N_(hi-1), T) by X - z yields exactly q_lo .. q_(hi-1), so the kernels are those of one GPU;
+//      what crosses the ranks is one record of a few field elements per round. ----
+struct OpeningSlice {
+    size_t lo, hi;     // quotient coefficients the rank commits (what commit_range hands its MSM)
+    size_t own_hi;     // numerator coefficients [lo, own_hi) the rank works on: its quotient range, the top slice the leading one too
+    bool any, top;
+};
+// the slice of rank r for commitment `index` of the round of two openings, from the table the coverage check gathered
+static OpeningSlice opening_slice(const ShardInfo* shard, uint32_t r, int index, size_t q_len) {
+    const uint64_t* rec = &shard->slices[6 * (size_t)r];
+    const bool grouped = rec[3] != 0;
+    const size_t first = grouped ? rec[2] : rec[0], points = grouped ? rec[3] : rec[1];
+    const bool mine = !grouped || r % 2u == (uint32_t)index;
+    OpeningSlice s;
+    s.lo = std::min(first, q_len);
+    s.hi = mine ? std::min(first + points, q_len) : s.lo;
+    s.any = s.hi > s.lo;
+    s.top = s.any && s.hi == q_len;
+    s.own_hi = s.top ? q_len + 1 : s.hi;
+    return s;
+}
+
+// T of the comment above for this rank's slice: `sums` holds every rank's sum_{j in its [lo, own_hi)} N_j z^j at
+// element at + r * stride
+static fr_h opening_carry(const ShardInfo* shard, int index, size_t q_len, const fr_h* sums, size_t at, size_t stride,
+                          const OpeningSlice& mine, const fr_h& z_inv) {
+    fr_h t = Fr::zero();
+    for (uint32_t r = 0; r < shard->ex->world; ++r) {
+        const OpeningSlice o = opening_slice(shard, r, index, q_len);
+        if (!o.any || o.lo < mine.hi) continue;   // an empty slice, or one that is not above this one
+        const fr_h& e = sums[at + (size_t)r * stride];
+        PLONK_REQUIRE(!Fr::geq_p(e), "prove: a rank's partial sum is not a reduced field element");
+        t = Fr::add(t, e);
+    }
+    return Fr::mul(t, Fr::pow_u64(z_inv, mine.hi));
+}
+
+// the numerator coefficients at hand in num[lo, own_hi) -> the slice's quotient coefficients in q[lo, hi)
+static void divide_slice(Ctx* ctx, ProverWorkspace* ws, fr_t* num, const OpeningSlice& os, const fr_h& carry, const fr_h& z,
+                         const fr_h& z_inv, const PowTab& z_tab, const PowTab& z_inv_tab, fr_t* q) {
+    if (!os.any) return;
+    size_t len = os.own_hi - os.lo;
+    if (!os.top) {   // the sum of everything above, as one more coefficient on top
+        HIP_CHECK(hipMemsetAsync(num + os.hi, 0, sizeof(fr_t), ctx->stream));
+        poly_poke(ctx, num, (uint32_t)os.hi, carry, false);
+        ++len;
+    }
+    poly_div_linear(ctx, num + os.lo, (uint32_t)len, z, z_inv, z_tab, z_inv_tab, ws->tmp.p, q + os.lo, ws->totals);
 }
 
 host::G1AffineH commit_checked(Ctx* ctx, const Srs* srs, const fr_t* coeffs_dev, size_t len) {
@@ -917,23 +974,62 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         pow_tables(ctx, pts, 4, (uint32_t)n + 8, ws->powtab, tabs);
     }
     HIP_CHECK(hipMemsetAsync(ws->wq2.p, 0, ns * sizeof(fr_t), st));
-    poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->tmp.p, ws->wq2.p, ws->totals);
-    commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2, /*hold_buckets=*/true);
+    const bool split = sharded(shard) && shard->ex->world > 1;   // rounds 4-5 by coefficient range (see opening_slice)
     fr_h e6[6];
-    {
+    const fr_t* eval_polys[6] = {CO[0], CO[1], CO[2], pk->coef.p + 5 * n, pk->coef.p + 6 * n, CO[3]};
+    const size_t eval_lens[6] = {n + 2, n + 2, n + 2, n, n, n + 3};
+    if (!split) {
+        poly_div_linear(ctx, CO[3], (uint32_t)n + 3, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->tmp.p, ws->wq2.p, ws->totals);
+        commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2, /*hold_buckets=*/true);
         EvalArgs ea;
         memset(&ea, 0, sizeof(ea));
-        const fr_t* polys[6] = {CO[0], CO[1], CO[2], pk->coef.p + 5 * n, pk->coef.p + 6 * n, CO[3]};
-        const uint32_t lens[6] = {(uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n + 2, (uint32_t)n, (uint32_t)n, (uint32_t)n + 3};
         for (int k = 0; k < 6; ++k) {
-            ea.coeffs[k] = polys[k];
-            ea.len[k] = lens[k];
+            ea.coeffs[k] = eval_polys[k];
+            ea.len[k] = (uint32_t)eval_lens[k];
             ea.lo[k] = tabs[k == 5 ? 2 : 0].lo;
             ea.hi[k] = tabs[k == 5 ? 2 : 0].hi;
         }
         poly_eval_batch(ctx, ea, 6, ws->evals.p, ws->partial);
         HIP_CHECK(hipMemcpyAsync(e6, ws->evals.p, 6 * sizeof(fr_t), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+    } else {
+        Exchange* ex = shard->ex;
+        const OpeningSlice os = opening_slice(shard, ex->rank, 0, n + 2);
+        // the six evaluations over this rank's SRS slice, and z's part of W_{zeta omega}'s numerator over its slice of that
+        // commitment: sums of c_i x^i with the exponents of the whole polynomial, so the ranks' sums simply add up
+        EvalArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        for (int k = 0; k < 7; ++k) {
+            const fr_t* poly = k < 6 ? eval_polys[k] : CO[3];
+            const size_t len = k < 6 ? eval_lens[k] : n + 3;
+            const size_t lo = k < 6 ? std::min(shard->lo, len) : os.lo;
+            const size_t hi = k < 6 ? std::min(shard->lo + srs->n, len) : os.own_hi;
+            ea.coeffs[k] = poly + lo;
+            ea.first[k] = (uint32_t)lo;
+            ea.len[k] = (uint32_t)(hi > lo ? hi - lo : 0);
+            ea.lo[k] = tabs[k >= 5 ? 2 : 0].lo;
+            ea.hi[k] = tabs[k >= 5 ? 2 : 0].hi;
+        }
+        poly_eval_batch(ctx, ea, 7, ws->evals.p, ws->partial);
+        constexpr size_t REC = 8;   // seven sums and a spare element per rank
+        ws->gath.ensure(REC * (size_t)ex->world);
+        HIP_CHECK(hipMemsetAsync(ws->evals.p + 7, 0, sizeof(fr_t), st));
+        ex->allgather(ws->evals.p, ws->gath.p, REC * sizeof(fr_t), st);
+        std::vector<fr_h> all(REC * (size_t)ex->world);
+        HIP_CHECK(hipMemcpyAsync(all.data(), ws->gath.p, all.size() * sizeof(fr_t), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int k = 0; k < 6; ++k) {
+            fr_h sum = Fr::zero();
+            for (uint32_t r = 0; r < ex->world; ++r) {
+                PLONK_REQUIRE(!Fr::geq_p(all[REC * r + k]), "prove: a rank's partial evaluation is not a reduced field element");
+                sum = Fr::add(sum, all[REC * r + k]);
+            }
+            e6[k] = sum;
+        }
+        const fr_h carry = os.any && !os.top ? opening_carry(shard, 0, n + 2, all.data(), 6, REC, os, zeta_omega_inv) : Fr::zero();
+        if (os.any) poly_copy(ctx, ws->wnum.p + os.lo, CO[3] + os.lo, os.own_hi - os.lo);   // wnum: free until round 5 builds its numerator
+        divide_slice(ctx, ws, ws->wnum.p, os, carry, zeta_omega, zeta_omega_inv, tabs[2], tabs[3], ws->wq2.p);
+        commit_add(ctx, srs, openings, ws->wq2.p, n + 2, ws->flag.p, shard, 2, /*hold_buckets=*/true);
     }
     const fr_h a_bar = e6[0], b_bar = e6[1], c_bar = e6[2], s1_bar = e6[3], s2_bar = e6[4], zw_bar = e6[5];
     tr.absorb_fr("a_zeta", a_bar);
@@ -984,11 +1080,40 @@ void prove_3wire(Ctx* ctx, const Pk* pk, const Srs* srs, const plonk_fr* a_ev, c
         term(pk->coef.p + 6 * n, n, v5);
         la.count = k;
         const uint32_t wlen = (uint32_t)n + 6;
-        poly_lincomb(ctx, la, ws->wnum.p, wlen);
         // (r + v (a - a_bar) + ...) / (X - zeta) (:800-809): the constants subtracted from the numerator (r(zeta), v a_bar,
         // ...) only change the remainder of the division, which is dropped -- the numerator is divided as it is
         HIP_CHECK(hipMemsetAsync(ws->wq.p, 0, ns * sizeof(fr_t), st));
-        poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
+        if (!split) {
+            poly_lincomb(ctx, la, ws->wnum.p, wlen);
+            poly_div_linear(ctx, ws->wnum.p, wlen, zeta, zeta_inv, tabs[0], tabs[1], ws->tmp.p, ws->wq.p, ws->totals);   // :809
+        } else {
+            Exchange* ex = shard->ex;
+            const OpeningSlice os = opening_slice(shard, ex->rank, 1, wlen - 1);
+            const size_t cnt = os.own_hi - os.lo;
+            if (os.any) {
+                for (uint32_t t = 0; t < la.count; ++t) {   // the numerator on [lo, own_hi) only
+                    const size_t len = la.len[t];
+                    la.p[t] += os.lo;
+                    la.len[t] = (uint32_t)(len > os.lo ? std::min(len, os.own_hi) - os.lo : 0);
+                }
+                poly_lincomb(ctx, la, ws->wnum.p + os.lo, (uint32_t)cnt);
+            }
+            EvalArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.coeffs[0] = ws->wnum.p + os.lo;
+            ea.first[0] = (uint32_t)os.lo;
+            ea.len[0] = (uint32_t)(os.any ? cnt : 0);
+            ea.lo[0] = tabs[0].lo;
+            ea.hi[0] = tabs[0].hi;
+            poly_eval_batch(ctx, ea, 1, ws->evals.p, ws->partial);
+            ws->gath.ensure(ex->world);
+            ex->allgather(ws->evals.p, ws->gath.p, sizeof(fr_t), st);
+            std::vector<fr_h> all(ex->world);
+            HIP_CHECK(hipMemcpyAsync(all.data(), ws->gath.p, all.size() * sizeof(fr_t), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            const fr_h carry = os.any && !os.top ? opening_carry(shard, 1, wlen - 1, all.data(), 0, 1, os, zeta_inv) : Fr::zero();
+            divide_slice(ctx, ws, ws->wnum.p, os, carry, zeta, zeta_inv, tabs[0], tabs[1], ws->wq.p);
+        }
         msm_batch_release(ctx, openings);   // W_{zeta omega}'s bucket kernel; W_zeta's sort runs beside it
         commit_add(ctx, srs, openings, ws->wq.p, wlen - 1, ws->flag.p, shard, 2);
         host::G1AffineH w[2];

@@ -31,6 +31,9 @@ struct ShardInfo {
     size_t lo = 0;
     Exchange* ex = nullptr;
     size_t global_end = 0;   // one past the last SRS point any rank holds (set by the prover)
+    // every rank's (first point, points) for its plain slice and its slices for b = 2 and 3, six words per rank
+    // (set by the prover from the coverage check: a rank knows which coefficients every other rank works on)
+    std::vector<uint64_t> slices;
     // Optional placement by groups: group_srs[b - 2] is this rank's slice for the rounds that commit b = 2 or 3
     // polynomials at once.  Commitment k of such a round is then computed by the ranks r with r % b == k alone,
     // whose slices tile the point range among THEM: each rank runs one larger MSM instead of b small ones.

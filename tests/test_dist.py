@@ -151,13 +151,13 @@ if os.environ.get("PLONK_TEST_GROUPED") == "1":
 prover = pa.Prover(wires, pk, srs, resident=True, comm=comm, shard=(lo, hi), groups=groups)
 proof = prover.prove(pis, blinding)
 calls, nbytes = comm.stats()
-# the coverage check, one all-gather per commitment MSM, and -- when round 3 is sharded by evaluation
-# point (a power-of-two number of ranks) -- the slices of the quotient polynomial
+# the coverage check, one all-gather per commitment MSM, the partial sums of rounds 4 and 5 (256 + 32 bytes) and --
+# when round 3 is sharded by evaluation point (a power-of-two number of ranks) -- the slices of the quotient polynomial
 point_sharded = world & (world - 1) == 0
-assert calls == 1 + 9 + (1 if point_sharded else 0), calls
+assert calls == 1 + 9 + 2 + (1 if point_sharded else 0), calls
 assert comm.host is None or comm.host.calls == calls
 if point_sharded:
-    assert nbytes == 48 + 9 * (64 + 256 * 192) + (4 * n // world) * 32, nbytes
+    assert nbytes == 48 + 9 * (64 + 256 * 192) + 256 + 32 + (4 * n // world) * 32, nbytes
 assert proof.to_bytes() == want, "sharded proof differs from the oracle's"
 assert prover.prove(pis, blinding).to_bytes() == proof.to_bytes()   # and again on warm buffers
 if case == "pi9" and world == 2:
@@ -290,8 +290,8 @@ def test_bench_starts_its_own_ranks():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["proof_sha256_16"] == one["config"]["proof_sha256_16"]
     assert two["steps"] == 2 and two["value"] > 0
-    ex = two["exchange"]   # event marks around the all-gathers: 9 MSM shares + coverage check + quotient slices per proof
-    assert ex["kind"] == "callback" and ex["all_gathers_per_proof"] == 11 and ex["stream_ms_per_proof_rank0"] > 0
+    ex = two["exchange"]   # event marks around the all-gathers: 9 MSM shares + coverage check + quotient slices + the sums of rounds 4, 5
+    assert ex["kind"] == "callback" and ex["all_gathers_per_proof"] == 13 and ex["stream_ms_per_proof_rank0"] > 0
     assert "exchange" not in one
     # asking for more ranks than WORLD_SIZE provides is an error, not a silent one-rank run
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
