@@ -57,6 +57,7 @@ struct NttPassArgs {
     uint32_t r_prev[NTT_MAX_PASSES];
     uint64_t batch_stride;
     uint64_t in_len;              // first sweep: elements from this index on are taken as zero and not read (0 = all are read)
+    uint32_t is_last;
     uint32_t xcd_remap;           // narrow tiles: column-adjacent tiles are given to workgroups of one XCD (see the kernel)
 };
 
@@ -93,17 +94,20 @@ struct LdsTile {
     }
 };
 
-// TWG: the sweep's own twiddles are read from sub_tw in memory (L2) instead of an LDS copy.  LAST: the last sweep
-// of a transform (rows contiguous in memory, output in natural order).
-template <bool TWG, bool LAST>
+// TWG: the sweep's own twiddles are read from sub_tw in memory (L2) instead of an LDS copy (a compile-time choice: a
+// pointer picked at run time between the two would make every twiddle read a generic-address load).
+// The kernel must stay within 128 VGPRs (four waves per SIMD): two workgroups then share a CU, and one computes while
+// the other loads or stores; with 131 a transform of 2^22 elements takes 8 % longer.
+template <bool TWG>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs p) {
+    const bool LAST = p.is_last != 0;
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const uint32_t R = p.R, log_c = p.log_c;
     const uint32_t Np = 1u << R, C = 1u << log_c;
     const uint32_t T = Np << log_c;
     // last sweep: rows are contiguous in memory -> image [c][d] with one element of padding per
     // row; other sweeps: image [d][c].
-    constexpr bool rowmajor = LAST;
+    const bool rowmajor = LAST;
     const uint32_t plane = rowmajor ? (C * (Np + 1)) : T;
     LdsTile tile_mem;
     tile_mem.a = lds;
@@ -547,8 +551,7 @@ NttPlan* ntt_get_plan(Ctx* ctx, uint32_t log_n, uint32_t flags) {
 
 // a tile and its twiddles take more than the 64 KiB of dynamic LDS a kernel may use by default (per device)
 static void ntt_raise_lds_limit() {
-    const void* variants[4] = {reinterpret_cast<const void*>(ntt_pass_kernel<false, false>), reinterpret_cast<const void*>(ntt_pass_kernel<false, true>),
-                               reinterpret_cast<const void*>(ntt_pass_kernel<true, false>), reinterpret_cast<const void*>(ntt_pass_kernel<true, true>)};
+    const void* variants[2] = {reinterpret_cast<const void*>(ntt_pass_kernel<false>), reinterpret_cast<const void*>(ntt_pass_kernel<true>)};
     for (const void* f : variants) HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
 }
 
@@ -608,13 +611,9 @@ static void ntt_launch(Ctx* ctx, hipStream_t stream, const NttPlan* pl, fr_t* da
         a.xcd_remap = (log_c < 2 && tiles >= 32) ? 1u : 0u;
         const size_t lds_bytes = ((elems * 36 + 15) & ~(size_t)15) + (tw_global ? 0 : ((size_t)1 << R) / 2 * 36) + 16;
         const dim3 grid(tiles, batch), block(NTT_THREADS);
-        if (tw_global) {
-            if (last) hipLaunchKernelGGL((ntt_pass_kernel<true, true>), grid, block, lds_bytes, stream, a);
-            else hipLaunchKernelGGL((ntt_pass_kernel<true, false>), grid, block, lds_bytes, stream, a);
-        } else {
-            if (last) hipLaunchKernelGGL((ntt_pass_kernel<false, true>), grid, block, lds_bytes, stream, a);
-            else hipLaunchKernelGGL((ntt_pass_kernel<false, false>), grid, block, lds_bytes, stream, a);
-        }
+        a.is_last = last ? 1u : 0u;
+        if (tw_global) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds_bytes, stream, a);
+        else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds_bytes, stream, a);
         HIP_CHECK(hipGetLastError());
         log_h += R;
     }

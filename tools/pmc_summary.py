@@ -8,16 +8,22 @@ tallies a 128-byte request as 64 bytes."""
 import collections
 import csv
 import glob
+import re
 import json
 import os
 import sys
+
+
+def kernel_name(full):
+    """plonk::ntt_pass_kernel<true, false>(plonk::NttPassArgs) -> ntt_pass_kernel: the compile-time variants of a kernel count as one"""
+    return re.sub(r"<.*", "", full.split("(")[0]).replace("void ", "").replace("plonk::", "").strip()
 
 
 def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0].replace("plonk::", "")].append(float(r["Counter_Value"]))
+            acc[kernel_name(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return acc
 
 

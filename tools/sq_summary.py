@@ -8,6 +8,7 @@ e.g.   sq_summary.py out.txt "msm 2^20=.../610_counter_collection.csv:13631456=m
 valu_issue_utilisation = SQ_INSTS_VALU / 1024 SIMDs * 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs): a wave64 VALU
 instruction occupies its SIMD's issue port for 4 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
 import collections
+import re
 import csv
 import sys
 
@@ -23,7 +24,7 @@ def main():
         units, kernels = float(units), kernels.split(",")
         per = collections.defaultdict(dict)   # (kernel, dispatch) -> counter -> value
         for r in csv.DictReader(open(path)):
-            name = r["Kernel_Name"].split("(")[0].replace("plonk::", "")
+            name = re.sub(r"<.*", "", r["Kernel_Name"].split("(")[0]).replace("void ", "").replace("plonk::", "").strip()   # compile-time variants count as one kernel
             per[(name, int(r["Dispatch_Id"]))][r["Counter_Name"]] = float(r["Counter_Value"])
         for k in kernels:
             last = 1
