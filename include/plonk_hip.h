@@ -229,7 +229,11 @@ int32_t plonk_comm_timing(plonk_comm* comm, int32_t enable, double* elapsed_ms);
  * (plonk_srs_from_tau_range or an upload of that slice) and the ranks' slices must tile the point
  * range in rank order (checked; PLONK_E_INVALID otherwise).  Every rank passes the same witness and
  * key and makes the same call; the ranks' shares of every MSM (the window sums of its reduction)
- * are all-gathered on the device and combined by every rank, so all ranks obtain the same proof. */
+ * are all-gathered on the device and combined by every rank, so all ranks obtain the same proof.
+ * With a power-of-two number of ranks (2, 4, 8) round 3 (prover.rs:339-574) is shared by evaluation point
+ * (each rank one residue class of the 4n coset; the quotient slices all-gathered); with two ranks and more
+ * the evaluations of round 4 (:577-641) are sums over the ranks' coefficient ranges, and each rank builds and
+ * divides the opening numerators of round 5 (:644-837) only on the slice it commits (partial sums all-gathered). */
 /* A sharded proof is a sequence of collectives (thirteen all-gathers with two or more ranks): a rank whose call returns anything but PLONK_OK
  * has left that sequence while its peers may already be queued in the next all-gather, so after a failed sharded
  * call the plonk_comm of EVERY rank must be destroyed and a new one created before further proofs (failures
