@@ -1010,23 +1010,29 @@ static void msm_enqueue(Ctx* ctx, MsmWorkspace* ws, int si, const MsmPoints& pts
 }
 
 // S_w = A_w + L * sum_i 2^i G_{w,i}; result = sum_w 2^(c w) S_w, from the sums of one reduction
-static host::G1XyzzH combine_sums(const g1_xyzz_t* sums, uint32_t c, uint32_t W, uint32_t nq, uint32_t log_chunks,
+static host::G1XyzzH combine_sums(const host::G1XyzzH* sums, uint32_t c, uint32_t W, uint32_t nq, uint32_t log_chunks,
                                   uint32_t chunk_log) {
     host::G1XyzzH acc = host::g1_identity();
     for (int w = (int)W - 1; w >= 0; --w) {
         if (w != (int)W - 1)
             for (uint32_t k = 0; k < c; ++k) acc = host::g1_double(acc);
-        const g1_xyzz_t* q = sums + (size_t)w * nq;
+        const host::G1XyzzH* q = sums + (size_t)w * nq;
         host::G1XyzzH g = host::g1_identity();
         for (int i = (int)log_chunks - 1; i >= 0; --i) {
             g = host::g1_double(g);
-            g = host::g1_add(g, xyzz_to_host(q[1 + i]));
+            g = host::g1_add(g, q[1 + i]);
         }
         for (uint32_t k = 0; k < chunk_log; ++k) g = host::g1_double(g);
-        g = host::g1_add(g, xyzz_to_host(q[0]));
+        g = host::g1_add(g, q[0]);
         acc = host::g1_add(acc, g);
     }
     return acc;
+}
+static host::G1XyzzH combine_sums(const g1_xyzz_t* sums, uint32_t c, uint32_t W, uint32_t nq, uint32_t log_chunks,
+                                  uint32_t chunk_log) {
+    std::vector<host::G1XyzzH> h((size_t)W * nq);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = xyzz_to_host(sums[i]);
+    return combine_sums(h.data(), c, W, nq, log_chunks, chunk_log);
 }
 
 // Wait for slot `si` and combine on the host; a sharded MSM adds up the shares of all ranks, in rank order.
@@ -1040,7 +1046,13 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
         return host::g1_to_affine(combine_sums(s.host_sums, s.c, s.W, s.nq, s.log_chunks, s.chunk_log));
     }
     HIP_CHECK(hipEventSynchronize(s.done_ev));
-    host::G1XyzzH acc = host::g1_identity();
+    // The combination is linear in the window sums: shares reduced with the same geometry (the usual case: equal
+    // slices) are first added sum by sum, and the doublings of the combination are paid once for all of them.
+    struct Group {
+        uint32_t hdr[6];
+        std::vector<host::G1XyzzH> sums;
+    };
+    std::vector<Group> groups;
     for (uint32_t r = 0; r < s.world; ++r) {
         const unsigned char* rec = s.host_gathered + (size_t)r * MSM_REC_BYTES;
         uint32_t hdr[6];
@@ -1049,9 +1061,23 @@ static host::G1AffineH msm_collect(MsmWorkspace* ws, int si) {
         if (hdr[1] < 1 || hdr[1] > 31 || hdr[2] < 1 || hdr[3] < 1 || (size_t)hdr[2] * hdr[3] > MSM_REC_SUMS ||
             hdr[4] + 1 != hdr[3] || hdr[5] > 31)
             throw Error(PLONK_E_INTERNAL, "msm: malformed share in the all-gathered records");
-        acc = host::g1_add(acc, combine_sums(reinterpret_cast<const g1_xyzz_t*>(rec + MSM_REC_HDR), hdr[1], hdr[2], hdr[3],
-                                             hdr[4], hdr[5]));
+        const g1_xyzz_t* sums = reinterpret_cast<const g1_xyzz_t*>(rec + MSM_REC_HDR);
+        const size_t count = (size_t)hdr[2] * hdr[3];
+        Group* g = nullptr;
+        for (Group& have : groups)
+            if (memcmp(have.hdr + 1, hdr + 1, 5 * sizeof(uint32_t)) == 0) g = &have;
+        if (!g) {
+            groups.emplace_back();
+            g = &groups.back();
+            memcpy(g->hdr, hdr, sizeof(hdr));
+            g->sums.resize(count);
+            for (size_t i = 0; i < count; ++i) g->sums[i] = xyzz_to_host(sums[i]);
+        } else {
+            for (size_t i = 0; i < count; ++i) g->sums[i] = host::g1_add(g->sums[i], xyzz_to_host(sums[i]));
+        }
     }
+    host::G1XyzzH acc = host::g1_identity();
+    for (const Group& g : groups) acc = host::g1_add(acc, combine_sums(g.sums.data(), g.hdr[1], g.hdr[2], g.hdr[3], g.hdr[4], g.hdr[5]));
     return host::g1_to_affine(acc);
 }
 
